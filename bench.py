@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- luma frames/s + achieved HBM GB/s of the HIP deblocking filter (BASELINE.json metric).
+
+A "step" = one launch of hevc_deblocking_filter_device over a batch of F distinct synthetic
+3840x2160 8-bit luma frames already resident in HBM (BASELINE config 4, QP 32, reference default
+bS, out of place src -> dst so every step sees the same input).  F x 8.3 MB x 2 >> 256 MB, so the
+Infinity Cache cannot hold the working set (SURVEY 7 "hard parts").
+
+Multi-GPU: one process per GPU (torch.distributed.run); frames shard frame-parallel with NO
+data-path collective -- torch.distributed (gloo) is used only for the barrier and the
+max-over-ranks of the elapsed time.  Scaling is weak: every rank filters its own F frames.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# load the product library (and with it /opt/rocm's HIP runtime) BEFORE torch is imported
+from gpu_video_codec_amd import _lib, deblock, synth  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_frame(w, h, sample_bytes):
+    """every sample read once + written once, every bS byte read once."""
+    return 2 * w * h * sample_bytes + deblock.num_vert_bs(w, h) + deblock.num_hor_bs(w, h)
+
+
+def make_frames(w, h, n, bit_depth, seed=1, n_base=4):
+    """n distinct frames: n_base generated frames x grid-aligned circular shifts (multiples of 8)."""
+    base = [synth.blocky_plane(w, h, seed=seed, frame=i, bit_depth=bit_depth) for i in range(min(n_base, n))]
+    out = np.empty((n, h, w), base[0].dtype)
+    for f in range(n):
+        b = base[f % len(base)]
+        k = f // len(base)
+        out[f] = np.roll(b, (8 * (5 * k % (h // 8)), 8 * (7 * k % (w // 8))), axis=(0, 1))
+    return out
+
+
+def cpu_baseline(frames, qp, bit_depth, budget_s, threads_all):
+    """Times the CPU checker (oracle 'port', luma only) on a bounded sample of the same frames:
+    single thread (the parity target) and OpenMP on all host cores, one warm-up each."""
+    from oracle import oracle
+    res = {}
+    for label, nt in (("t1", 1), ("omp", threads_all)):
+        oracle.filter_plane(frames[0], qp, bit_depth=bit_depth, threads=nt)  # warm-up (OpenMP team start)
+        n, t0 = 0, time.perf_counter()
+        times = []
+        while True:
+            f = frames[n % len(frames)]
+            fr = oracle.Frame(f, bit_depth=bit_depth)     # ctor untimed, like main.cu:40
+            a = time.perf_counter()
+            fr.filter(qp, planes=oracle.PLANE_Y, threads=nt)  # window = filter only (main.cu:41-43)
+            times.append(time.perf_counter() - a)
+            fr.close()
+            n += 1
+            if time.perf_counter() - t0 > budget_s / 2 or n >= 400:
+                break
+        res[label] = {"threads": nt, "frames": n, "min_s": min(times), "median_s": float(np.median(times))}
+    out = {"value": 1.0 / res["t1"]["median_s"], "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d luma frames 1T + %d frames OpenMP(%d) of the benchmark batch, filter-only window, median"
+                     % (res["t1"]["frames"], res["omp"]["frames"], threads_all),
+           "t1_min_s": res["t1"]["min_s"], "t1_median_s": res["t1"]["median_s"],
+           "omp_threads": threads_all, "omp_value": 1.0 / res["omp"]["median_s"],
+           "omp_min_s": res["omp"]["min_s"], "omp_median_s": res["omp"]["median_s"]}
+    # the reference's own code (Y+U+V of a 4:2:0 frame; it cannot filter luma alone), when oracle/_ref travelled
+    try:
+        if oracle.have_ref() and bit_depth == 8:
+            h, w = frames[0].shape
+            u = synth.blocky_plane(w // 2, h // 2, seed=11)
+            buf = oracle.join_yuv420(frames[0], u, u)
+            ts = []
+            for _ in range(5):
+                rf = oracle.RefFrame(buf, w, h, qp)
+                a = time.perf_counter()
+                rf.filter(1)
+                ts.append(time.perf_counter() - a)
+                rf.close()
+            out["reference_yuv420_1t_median_s"] = float(np.median(ts[1:]))
+    except Exception as e:  # the reference build is optional evidence, never fatal
+        out["reference_error"] = str(e)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--variant", choices=["auto", "generic", "packed"], default="auto")
+    ap.add_argument("--cpu-budget-s", type=float, default=16.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # gloo: control plane only, the data path has no collective
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    variant = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "packed": _lib.KERNEL_PACKED}[args.variant]
+    w, h, F, bd = args.width, args.height, args.frames, args.bit_depth
+    sb = 1 if bd == 8 else 2
+    ndev = deblock.device_count()
+    if ndev <= 0:
+        raise SystemExit("bench.py needs a HIP device: the deblocking filter has no CPU fallback")
+    ctx = deblock.Context(local_rank % ndev)
+    frames = make_frames(w, h, F, bd, seed=1 + rank)
+    batch = deblock.DeviceBatch(ctx, w, h, F, bit_depth=bd)
+    batch.upload_all(frames)
+    planes = batch.planes()
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    if args.warmup > 0:
+        ctx.run_timed([planes], args.qp, args.warmup, variant=variant)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = ctx.run_timed([planes], args.qp, args.steps, variant=variant)  # K launches, one sync at the end
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # parity spot check on what the timed launches wrote (not timed)
+    from oracle import oracle
+    bit_exact = True
+    for f in sorted({0, F // 2, F - 1}):
+        bit_exact &= bool(np.array_equal(batch.download_frame(f), oracle.filter_plane(frames[f], args.qp, bit_depth=bd)))
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * F * args.steps / elapsed
+    abytes = algorithmic_bytes_per_frame(w, h, sb) * F
+    kavg_ms = float(np.mean(kernel_ms))
+    achieved = abytes / (kavg_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "luma_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32" if args.variant == "generic" else "int16", "data": "synthetic",
+        "config": {"workload": "synthetic %dx%d %d-bit luma deblock, QP %d, default bS, %d frames/GPU/step, device-resident, src->dst"
+                               % (w, h, bd, args.qp, F),
+                   "frames_per_gpu": F, "kernel_variant": args.variant, "parallelism": "frame-parallel x%d, no collective" % world},
+        "bit_exact_vs_oracle": bit_exact,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel_avg_ms": kavg_ms, "kernel_min_ms": float(np.min(kernel_ms)),
+                     "algorithmic_bytes_per_launch": abytes,
+                     "read_GBps": (abytes - w * h * sb * F) / (kavg_ms * 1e-3) / 1e9},
+    }
+    if rank == 0 and world == 1:
+        if not args.no_e2e:
+            # end-to-end (PCIe-inclusive) rate of the host-frame operator; never `value`
+            yy = frames[0].copy()
+            ctx.filter_frame(yy, qp=args.qp, bit_depth=bd)
+            ts = []
+            for _ in range(5):
+                yy = frames[0].copy()
+                a = time.perf_counter()
+                tm = ctx.filter_frame(yy, qp=args.qp, bit_depth=bd)
+                ts.append(time.perf_counter() - a)
+            out["e2e_host_frame"] = {"frames_per_s": 1.0 / float(np.median(ts)), "exec_s": tm["exec_s"],
+                                     "copy_s": tm["copy_s"], "total_s": tm["total_s"]}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames[: min(F, 8)], args.qp, bd, args.cpu_budget_s, os.cpu_count() or 1)
+    batch.free()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if not bit_exact:
+        raise SystemExit("bench: HIP output differs from the oracle")
+
+
+if __name__ == "__main__":
+    main()

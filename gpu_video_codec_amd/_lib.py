@@ -1,0 +1,122 @@
+"""ctypes loader for the product library libhevcdbk.so (C ABI: include/hevc_deblock.h).
+
+Fails loudly when the library is missing: there is no Python or CPU fallback for the filter.
+The library is linked against /opt/rocm's HIP runtime (RUNPATH); loading it before `import torch`
+makes that runtime (the one hipcc / rocprofv3 match) the single HIP runtime of the process.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhevcdbk.so")
+
+OK, ERR_FILE_SIZE, ERR_DIMENSIONS, ERR_BS_SIZE, ERR_HIP, ERR_ARG, ERR_NOMEM, ERR_IO, ERR_UNSUPPORTED = \
+    0, -1, -2, -3, -4, -5, -6, -7, -8
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED = 0, 1, 2
+
+# every symbol include/hevc_deblock.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "hevcdbk_strerror", "hevcdbk_device_count", "hevcdbk_create", "hevcdbk_destroy", "hevcdbk_last_error",
+    "hevcdbk_get_device_info", "hevcdbk_default_tc_table", "hevcdbk_default_beta_table",
+    "hevcdbk_num_vert_bs", "hevcdbk_num_hor_bs", "hevcdbk_default_bs",
+    "hevc_deblocking_filter", "hevc_deblocking_filter_device",
+    "hevcdbk_device_malloc", "hevcdbk_device_free", "hevcdbk_host_malloc_pinned", "hevcdbk_host_free_pinned",
+    "hevcdbk_memcpy_h2d", "hevcdbk_memcpy_d2h", "hevcdbk_memcpy_d2d", "hevcdbk_memset_d",
+    "hevcdbk_synchronize", "hevcdbk_compute_stream", "hevcdbk_device_run_timed", "hevcdbk_execute_gpu",
+]
+
+
+class Frame(C.Structure):
+    _fields_ = [("width", C.c_uint), ("height", C.c_uint), ("bit_depth", C.c_uint), ("sample_bytes", C.c_uint),
+                ("plane", C.c_void_p * 3), ("pitch", C.c_size_t * 3)]
+
+
+class Bs(C.Structure):
+    _fields_ = [("vert", C.c_void_p), ("n_vert", C.c_size_t), ("hor", C.c_void_p), ("n_hor", C.c_size_t),
+                ("chroma_vert", C.c_void_p), ("n_chroma_vert", C.c_size_t),
+                ("chroma_hor", C.c_void_p), ("n_chroma_hor", C.c_size_t)]
+
+
+class Qp(C.Structure):
+    _fields_ = [("qp", C.c_uint), ("map", C.c_void_p), ("map_stride", C.c_uint), ("ctu_log2", C.c_uint)]
+
+
+class Tables(C.Structure):
+    _fields_ = [("tc", C.c_void_p), ("beta", C.c_void_p)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("exec_s", C.c_double), ("total_s", C.c_double), ("copy_s", C.c_double), ("pipelined_s", C.c_double)]
+
+
+class DevicePlanes(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("pitch", C.c_size_t), ("frame_stride", C.c_size_t),
+                ("n_frames", C.c_uint), ("plane_w", C.c_uint), ("plane_h", C.c_uint),
+                ("bit_depth", C.c_uint), ("sample_bytes", C.c_uint), ("is_chroma", C.c_int),
+                ("vert_bs", C.c_void_p), ("hor_bs", C.c_void_p),
+                ("vert_bs_stride", C.c_size_t), ("hor_bs_stride", C.c_size_t),
+                ("qp_map", C.c_void_p), ("qp_map_stride", C.c_uint), ("ctu_log2", C.c_uint),
+                ("qp_map_frame_stride", C.c_size_t)]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 256), ("gcn_arch", C.c_char * 64), ("compute_units", C.c_int),
+                ("wavefront_size", C.c_int), ("max_threads_per_block", C.c_int),
+                ("total_global_mem", C.c_size_t), ("shared_mem_per_block", C.c_size_t),
+                ("total_const_mem", C.c_size_t)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C library.  Raises if it has not been built (see __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libhevcdbk.so is missing (%s): build it with `make -C gpu_video_codec_amd/csrc` or "
+                "__graft_entry__.build(); the deblocking filter has no CPU/Python fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        L.hevcdbk_strerror.restype = C.c_char_p
+        L.hevcdbk_last_error.restype = C.c_char_p
+        L.hevcdbk_last_error.argtypes = [C.c_void_p]
+        L.hevcdbk_default_tc_table.restype = C.POINTER(C.c_uint * 52)
+        L.hevcdbk_default_beta_table.restype = C.POINTER(C.c_uint * 52)
+        L.hevcdbk_num_vert_bs.restype = C.c_size_t
+        L.hevcdbk_num_hor_bs.restype = C.c_size_t
+        L.hevcdbk_num_vert_bs.argtypes = [C.c_uint, C.c_uint]
+        L.hevcdbk_num_hor_bs.argtypes = [C.c_uint, C.c_uint]
+        L.hevcdbk_default_bs.argtypes = [C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]
+        L.hevcdbk_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.hevcdbk_destroy.argtypes = [C.c_void_p]
+        L.hevcdbk_destroy.restype = None
+        L.hevcdbk_get_device_info.argtypes = [C.c_void_p, C.POINTER(DeviceInfo)]
+        L.hevc_deblocking_filter.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Bs), C.POINTER(Qp),
+                                             C.POINTER(Tables), C.POINTER(Timing)]
+        L.hevc_deblocking_filter_device.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint,
+                                                    C.POINTER(Tables), C.c_int, C.c_void_p]
+        L.hevcdbk_device_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.hevcdbk_device_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.hevcdbk_host_malloc_pinned.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.hevcdbk_host_free_pinned.argtypes = [C.c_void_p, C.c_void_p]
+        L.hevcdbk_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.hevcdbk_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.hevcdbk_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.hevcdbk_memset_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]
+        L.hevcdbk_synchronize.argtypes = [C.c_void_p]
+        L.hevcdbk_compute_stream.argtypes = [C.c_void_p]
+        L.hevcdbk_compute_stream.restype = C.c_void_p
+        L.hevcdbk_device_run_timed.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint, C.c_uint,
+                                               C.POINTER(Tables), C.c_int, C.c_uint, C.POINTER(C.c_float)]
+        L.hevcdbk_execute_gpu.argtypes = [C.c_char_p, C.c_char_p, C.c_uint, C.c_uint, C.c_uint,
+                                          C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int]
+        _lib = L
+    return _lib
+
+
+class DeblockError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = lib().hevcdbk_strerror(code).decode()
+        super().__init__("%s (code %d)%s" % (msg, code, (": " + detail) if detail else ""))

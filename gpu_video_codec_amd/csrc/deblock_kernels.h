@@ -1,0 +1,31 @@
+/* deblock_kernels.h -- launch interface between the C-ABI host driver and the HIP kernels. */
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+struct DbkArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    long long pitch;        /* bytes */
+    long long frame_stride; /* bytes */
+    int plane_w, plane_h;   /* samples */
+    int nbx, nby;           /* offset blocks: plane_w/8+1, plane_h/8+1 (cpu.h:141-142) */
+    int n_frames;
+    const uint8_t *vert_bs, *hor_bs;
+    long long vert_bs_stride, hor_bs_stride; /* bytes per frame, 0 = shared */
+    int n_vert, n_hor;
+    int vstride, hstride;   /* plane_w/8+1 (cpu.h:161), plane_w/8 (cpu.h:289) */
+    int limit_bx, limit_by; /* guards of hor2 / ver2 (luma limits for chroma) */
+    int tc, beta;           /* scalar-QP values, already << (bit_depth-8) */
+    int max_v, shift;
+    const uint8_t *qp_map;
+    int map_stride, ctu_log2;
+    long long map_frame_stride;
+    uint8_t tc_tab[52], beta_tab[52];
+};
+
+/* one lane per offset block, 32-bit arithmetic; every operand kind */
+hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, hipStream_t stream);
+/* packed 16-bit arithmetic kernel: 8-bit samples, scalar QP, luma or chroma */
+hipError_t dbk_launch_packed(const DbkArgs &a, bool chroma, hipStream_t stream);
+bool dbk_packed_supports(const DbkArgs &a, int sample_bytes);

@@ -1,0 +1,138 @@
+/*
+ * deblock_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4, wave64).
+ *
+ * Mapping shared by all kernels: one lane owns one offset 8x8 block (SURVEY 8 layout), a wave
+ * owns 64 consecutive blocks of one block row, so every row load of a wave is one contiguous
+ * 64 x 8 B (8-bit) / 64 x 16 B (16-bit) span of the un-padded plane.  The reference's 4-sample
+ * zero padding (cpu.h:55-71) is virtual: out-of-image halves/rows are materialised as zeros in
+ * registers and never stored.  Blocks are mutually independent, so src == dst
+ * is race-free.
+ *
+ * No MFMA: this is byte/int16 arithmetic on a streaming in-place filter; the bound is HBM.
+ */
+#include <hip/hip_runtime.h>
+
+#include "deblock_core.h"
+#include "deblock_kernels.h"
+
+namespace {
+
+/* ------------------------------------------------------------------------------------------ */
+/* generic kernel: 32-bit arithmetic, uint8 / uint16 samples, luma / chroma, scalar QP / map   */
+
+template <typename T>
+struct Quad; /* 4 consecutive samples as one memory word */
+template <>
+struct Quad<uint8_t> {
+    using W = uint32_t;
+    static __device__ __forceinline__ void unpack(W w, int &a, int &b, int &c, int &d)
+    {
+        a = w & 0xff; b = (w >> 8) & 0xff; c = (w >> 16) & 0xff; d = w >> 24;
+    }
+    static __device__ __forceinline__ W pack(int a, int b, int c, int d)
+    {
+        return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+    }
+    static __device__ __forceinline__ W zero() { return 0u; }
+};
+template <>
+struct Quad<uint16_t> {
+    using W = uint2;
+    static __device__ __forceinline__ void unpack(W w, int &a, int &b, int &c, int &d)
+    {
+        a = w.x & 0xffff; b = w.x >> 16; c = w.y & 0xffff; d = w.y >> 16;
+    }
+    static __device__ __forceinline__ W pack(int a, int b, int c, int d)
+    {
+        return make_uint2((uint32_t)a | ((uint32_t)b << 16), (uint32_t)c | ((uint32_t)d << 16));
+    }
+    static __device__ __forceinline__ W zero() { return make_uint2(0u, 0u); }
+};
+
+template <typename T, bool CHROMA, bool QPMAP>
+__global__ __launch_bounds__(256) void dbk_generic_kernel(const DbkArgs a)
+{
+    using Q = Quad<T>;
+    using W = typename Q::W;
+    const int bx = blockIdx.x * 64 + threadIdx.x;
+    const int by = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (bx >= a.nbx || by >= a.nby) return;
+
+    const uint8_t *src = a.src + (long long)f * a.frame_stride;
+    uint8_t *dst = a.dst + (long long)f * a.frame_stride;
+    const int x0 = bx * 8 - 4, y0 = by * 8 - 4; /* image coords of the block's (0,0) */
+    const bool lv = bx > 0;                     /* cols 0..3 inside the image */
+    const bool rv = bx < a.nbx - 1;             /* cols 4..7 inside the image */
+
+    int v[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int y = y0 + r;
+        const bool rowv = (unsigned)y < (unsigned)a.plane_h;
+        const uint8_t *row = src + (long long)y * a.pitch + (long long)x0 * (int)sizeof(T);
+        W l = Q::zero(), rr = Q::zero();
+        if (rowv && lv) l = *reinterpret_cast<const W *>(row);
+        if (rowv && rv) rr = *reinterpret_cast<const W *>(row + 4 * sizeof(T));
+        Q::unpack(l, v[r][0], v[r][1], v[r][2], v[r][3]);
+        Q::unpack(rr, v[r][4], v[r][5], v[r][6], v[r][7]);
+    }
+
+    const dbk::BlockBs bs =
+        dbk::load_block_bs(a.vert_bs + (long long)f * a.vert_bs_stride, a.hor_bs + (long long)f * a.hor_bs_stride,
+                           bx, by, a.vstride, a.hstride, a.limit_bx, a.limit_by, a.n_vert, a.n_hor);
+
+    dbk::BlockQp q;
+    if constexpr (QPMAP) {
+        const uint8_t *map = a.qp_map + (long long)f * a.map_frame_stride;
+        const int sc = CHROMA ? 2 : 1, lw = a.plane_w * sc, lh = a.plane_h * sc;
+        /* P0 / Q0 of line 0 of each segment, plane coords (same positions as oracle seg_tc_beta) */
+        const int qp0 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 3, y0 + 0, x0 + 4, y0 + 0);
+        const int qp1 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 3, y0 + 4, x0 + 4, y0 + 4);
+        const int qp2 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 0, y0 + 3, x0 + 0, y0 + 4);
+        const int qp3 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 4, y0 + 3, x0 + 0, y0 + 4);
+        q.tc[0] = a.tc_tab[qp0] << a.shift; q.beta[0] = a.beta_tab[qp0] << a.shift;
+        q.tc[1] = a.tc_tab[qp1] << a.shift; q.beta[1] = a.beta_tab[qp1] << a.shift;
+        q.tc[2] = a.tc_tab[qp2] << a.shift; q.beta[2] = a.beta_tab[qp2] << a.shift;
+        q.tc[3] = a.tc_tab[qp3] << a.shift; q.beta[3] = a.beta_tab[qp3] << a.shift;
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++) { q.tc[s] = a.tc; q.beta[s] = a.beta; }
+    }
+
+    dbk::filter_block_generic<CHROMA>(v, bs, q, a.max_v);
+
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int y = y0 + r;
+        const bool rowv = (unsigned)y < (unsigned)a.plane_h;
+        uint8_t *row = dst + (long long)y * a.pitch + (long long)x0 * (int)sizeof(T);
+        if (rowv && lv) *reinterpret_cast<W *>(row) = Q::pack(v[r][0], v[r][1], v[r][2], v[r][3]);
+        if (rowv && rv) *reinterpret_cast<W *>(row + 4 * sizeof(T)) = Q::pack(v[r][4], v[r][5], v[r][6], v[r][7]);
+    }
+}
+
+template <typename T, bool CHROMA>
+hipError_t launch_generic_t(const DbkArgs &a, hipStream_t stream)
+{
+    dim3 block(64, 4, 1);
+    dim3 grid((a.nbx + 63) / 64, (a.nby + 3) / 4, a.n_frames);
+    if (a.qp_map)
+        hipLaunchKernelGGL((dbk_generic_kernel<T, CHROMA, true>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((dbk_generic_kernel<T, CHROMA, false>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+} /* namespace */
+
+hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, hipStream_t stream)
+{
+    if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
+    if (sample_bytes == 1)
+        return chroma ? launch_generic_t<uint8_t, true>(a, stream) : launch_generic_t<uint8_t, false>(a, stream);
+    return chroma ? launch_generic_t<uint16_t, true>(a, stream) : launch_generic_t<uint16_t, false>(a, stream);
+}
+
+bool dbk_packed_supports(const DbkArgs &, int) { return false; }
+hipError_t dbk_launch_packed(const DbkArgs &, bool, hipStream_t) { return hipErrorNotSupported; }

@@ -1,0 +1,297 @@
+"""Python binding of the C ABI (include/hevc_deblock.h) -- plumbing for tests and bench.py.
+
+The compute path is libhevcdbk.so (hand-written HIP, gfx950).  Nothing here computes pixels.
+
+`ReadYuvFrame` mirrors the reference's class of the same name
+(hevc_deblocking_filter_cpu.h:33-132, 995-1018: ctor(file, w, h, Qp) / SetBoundaryStrenght /
+DeblockingFilter / Save) so that tests read like a test of the reference would; its
+DeblockingFilter() runs on the GPU through hevc_deblocking_filter().
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (DeblockError, KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED)  # noqa: F401
+
+
+def _chk(rc, ctx=None):
+    if rc != 0:
+        detail = ""
+        if ctx is not None and rc == _lib.ERR_HIP:
+            detail = _lib.lib().hevcdbk_last_error(ctx).decode()
+        raise DeblockError(rc, detail)
+
+
+def num_vert_bs(w, h):
+    return int(_lib.lib().hevcdbk_num_vert_bs(w, h))
+
+
+def num_hor_bs(w, h):
+    return int(_lib.lib().hevcdbk_num_hor_bs(w, h))
+
+
+def default_bs(w, h):
+    v = np.empty(num_vert_bs(w, h), np.uint8)
+    hh = np.empty(num_hor_bs(w, h), np.uint8)
+    _chk(_lib.lib().hevcdbk_default_bs(w, h, v.ctypes.data, hh.ctypes.data))
+    return v, hh
+
+
+def default_tables():
+    L = _lib.lib()
+    return (np.array(L.hevcdbk_default_tc_table().contents, np.uint32),
+            np.array(L.hevcdbk_default_beta_table().contents, np.uint32))
+
+
+def device_count():
+    return int(_lib.lib().hevcdbk_device_count())
+
+
+def _tables(tc, beta):
+    if tc is None and beta is None:
+        return None, []
+    t = _lib.Tables()
+    keep = []
+    for name, arr in (("tc", tc), ("beta", beta)):
+        if arr is not None:
+            a = np.ascontiguousarray(arr, np.uint32)
+            keep.append(a)
+            setattr(t, name, a.ctypes.data)
+    return t, keep
+
+
+class DeviceBuffer:
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        _chk(_lib.lib().hevcdbk_device_malloc(ctx.handle, self.nbytes, C.byref(p)), ctx.handle)
+        self.ptr = p.value
+
+    def upload(self, arr, offset=0):
+        a = np.ascontiguousarray(arr)
+        assert offset + a.nbytes <= self.nbytes
+        _chk(_lib.lib().hevcdbk_memcpy_h2d(self.ctx.handle, self.ptr + offset, a.ctypes.data, a.nbytes), self.ctx.handle)
+
+    def download(self, nbytes=None, offset=0, dtype=np.uint8):
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = np.empty(nbytes, np.uint8)
+        _chk(_lib.lib().hevcdbk_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr + offset, nbytes), self.ctx.handle)
+        return out.view(dtype)
+
+    def free(self):
+        if self.ptr:
+            _lib.lib().hevcdbk_device_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """hevcdbk_context: one per HIP device; owns the compute stream and the two copy streams."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _chk(_lib.lib().hevcdbk_create(device, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            _lib.lib().hevcdbk_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def device_info(self):
+        i = _lib.DeviceInfo()
+        _chk(_lib.lib().hevcdbk_get_device_info(self.handle, C.byref(i)))
+        return {"name": i.name.decode(), "gcn_arch": i.gcn_arch.decode(), "compute_units": i.compute_units,
+                "wavefront_size": i.wavefront_size, "total_global_mem": i.total_global_mem}
+
+    def synchronize(self):
+        _chk(_lib.lib().hevcdbk_synchronize(self.handle), self.handle)
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    # -- hevc_deblocking_filter(frame, bS, QP, tables): host planes, in place --------------------
+    def filter_frame(self, y, u=None, v=None, *, qp, bit_depth=8, vert_bs=None, hor_bs=None,
+                     chroma_vert_bs=None, chroma_hor_bs=None, qp_map=None, ctu_log2=6,
+                     tc_table=None, beta_table=None, check_sizes=True):
+        """Filters the given 2-D numpy planes IN PLACE (they must be writable, C-contiguous rows).
+        Returns the reference's timing triple as a dict."""
+        sample_bytes = y.dtype.itemsize
+        fr = _lib.Frame()
+        fr.height, fr.width = y.shape
+        fr.bit_depth, fr.sample_bytes = bit_depth, sample_bytes
+        planes = [y] + ([u, v] if u is not None else [])
+        for i, p in enumerate(planes):
+            assert p.flags.writeable and p.strides[1] == p.itemsize
+            fr.plane[i] = p.ctypes.data
+            fr.pitch[i] = p.strides[0]
+        bs = None
+        keep = []
+        if vert_bs is not None or chroma_vert_bs is not None:
+            bs = _lib.Bs()
+            for nm, arr in (("vert", vert_bs), ("hor", hor_bs), ("chroma_vert", chroma_vert_bs), ("chroma_hor", chroma_hor_bs)):
+                if arr is not None:
+                    a = np.ascontiguousarray(arr, np.uint8)
+                    keep.append(a)
+                    setattr(bs, nm, a.ctypes.data)
+                    setattr(bs, "n_" + nm, a.size)
+        q = _lib.Qp()
+        q.qp, q.ctu_log2 = int(qp), ctu_log2
+        if qp_map is not None:
+            m = np.ascontiguousarray(qp_map, np.uint8)
+            keep.append(m)
+            q.map, q.map_stride = m.ctypes.data, m.shape[1]
+        t, k2 = _tables(tc_table, beta_table)
+        tm = _lib.Timing()
+        rc = _lib.lib().hevc_deblocking_filter(self.handle, C.byref(fr), None if bs is None else C.byref(bs),
+                                               C.byref(q), None if t is None else C.byref(t), C.byref(tm))
+        _chk(rc, self.handle)
+        return {"exec_s": tm.exec_s, "total_s": tm.total_s, "copy_s": tm.copy_s, "pipelined_s": tm.pipelined_s}
+
+    # -- device-resident operator ---------------------------------------------------------------
+    def filter_device(self, planes, qp, *, tc_table=None, beta_table=None, variant=KERNEL_AUTO):
+        t, _k = _tables(tc_table, beta_table)
+        rc = _lib.lib().hevc_deblocking_filter_device(self.handle, C.byref(planes), int(qp),
+                                                      None if t is None else C.byref(t), variant, None)
+        _chk(rc, self.handle)
+
+    def run_timed(self, planes_list, qp, steps, *, variant=KERNEL_AUTO, tc_table=None, beta_table=None):
+        """`steps` back-to-back launches of every plane in planes_list; per-step kernel ms (HIP events)."""
+        arr = (_lib.DevicePlanes * len(planes_list))(*planes_list)
+        ms = (C.c_float * steps)()
+        t, _k = _tables(tc_table, beta_table)
+        rc = _lib.lib().hevcdbk_device_run_timed(self.handle, arr, len(planes_list), int(qp),
+                                                 None if t is None else C.byref(t), variant, steps, ms)
+        _chk(rc, self.handle)
+        return np.array(ms, np.float64)
+
+
+class DeviceBatch:
+    """n_frames planes of identical geometry resident in HBM (src and dst), plus their bS arrays.
+    This is the layout bench.py times: frame f at base + f*frame_stride, tight pitch."""
+
+    def __init__(self, ctx, plane_w, plane_h, n_frames, *, bit_depth=8, sample_bytes=None, is_chroma=False,
+                 in_place=False, per_frame_bs=True):
+        self.ctx = ctx
+        self.w, self.h, self.n = plane_w, plane_h, n_frames
+        self.bit_depth = bit_depth
+        self.sb = sample_bytes or (1 if bit_depth == 8 else 2)
+        self.dtype = np.uint8 if self.sb == 1 else np.uint16
+        self.is_chroma = is_chroma
+        self.pitch = plane_w * self.sb
+        self.frame_bytes = self.pitch * plane_h
+        self.src = ctx.alloc(self.frame_bytes * n_frames)
+        self.dst = self.src if in_place else ctx.alloc(self.frame_bytes * n_frames)
+        self.nv, self.nh = num_vert_bs(plane_w, plane_h), num_hor_bs(plane_w, plane_h)
+        self.per_frame_bs = per_frame_bs
+        nb = n_frames if per_frame_bs else 1
+        self.vert = ctx.alloc(self.nv * nb)
+        self.hor = ctx.alloc(self.nh * nb)
+        dv, dh = default_bs(plane_w, plane_h)
+        self.vert.upload(np.tile(dv, nb))
+        self.hor.upload(np.tile(dh, nb))
+        self.qp_map = None
+        self.map_stride = 0
+        self.ctu_log2 = 6
+
+    def upload_frame(self, f, plane):
+        a = np.ascontiguousarray(plane, self.dtype)
+        assert a.shape == (self.h, self.w)
+        self.src.upload(a, f * self.frame_bytes)
+
+    def upload_all(self, frames):
+        a = np.ascontiguousarray(frames, self.dtype)
+        assert a.shape == (self.n, self.h, self.w)
+        self.src.upload(a)
+
+    def set_bs(self, f, vert, hor):
+        assert self.per_frame_bs or f == 0
+        self.vert.upload(np.ascontiguousarray(vert, np.uint8), f * self.nv)
+        self.hor.upload(np.ascontiguousarray(hor, np.uint8), f * self.nh)
+
+    def set_qp_map(self, qmap, ctu_log2=6):
+        m = np.ascontiguousarray(qmap, np.uint8)
+        self.qp_map = self.ctx.alloc(m.nbytes)
+        self.qp_map.upload(m)
+        self.map_stride, self.ctu_log2 = m.shape[1], ctu_log2
+
+    def planes(self):
+        p = _lib.DevicePlanes()
+        p.src, p.dst = self.src.ptr, self.dst.ptr
+        p.pitch, p.frame_stride, p.n_frames = self.pitch, self.frame_bytes, self.n
+        p.plane_w, p.plane_h = self.w, self.h
+        p.bit_depth, p.sample_bytes, p.is_chroma = self.bit_depth, self.sb, int(self.is_chroma)
+        p.vert_bs, p.hor_bs = self.vert.ptr, self.hor.ptr
+        p.vert_bs_stride = self.nv if self.per_frame_bs else 0
+        p.hor_bs_stride = self.nh if self.per_frame_bs else 0
+        if self.qp_map is not None:
+            p.qp_map, p.qp_map_stride, p.ctu_log2 = self.qp_map.ptr, self.map_stride, self.ctu_log2
+        return p
+
+    def download_frame(self, f, which="dst"):
+        buf = self.dst if which == "dst" else self.src
+        return buf.download(self.frame_bytes, f * self.frame_bytes, self.dtype).reshape(self.h, self.w)
+
+    def free(self):
+        for b in (self.src, self.dst, self.vert, self.hor, self.qp_map):
+            if b is not None and b.ptr:
+                b.free()
+
+
+class ReadYuvFrame:
+    """Same call surface as the reference class (cpu.h:33), executed by the HIP library.
+
+    ctor(file_name, width, height, Qp=20)            cpu.h:35
+    SetBoundaryStrenght(vert_bs, hor_bs)              cpu.h:120  (luma only)
+    DeblockingFilter()                                cpu.h:134  -> hevc_deblocking_filter on the GPU
+    Save(output_file_name)                            cpu.h:995
+    Errors are raised as DeblockError carrying the reference's message text.
+    """
+
+    def __init__(self, file_name, width, height, Qp=20, ctx=None):
+        with open(file_name, "rb") as fh:
+            buf = fh.read()
+        if len(buf) != 3 * width * height // 2:            # cpu.h:43-45
+            raise DeblockError(_lib.ERR_FILE_SIZE)
+        if width % 8 != 0 or height % 8 != 0:               # cpu.h:46-48
+            raise DeblockError(_lib.ERR_DIMENSIONS)
+        a = np.frombuffer(buf, np.uint8)
+        ysz, csz = width * height, width * height // 4
+        self.y = a[:ysz].reshape(height, width).copy()
+        self.u = a[ysz:ysz + csz].reshape(height // 2, width // 2).copy()
+        self.v = a[ysz + csz:].reshape(height // 2, width // 2).copy()
+        self.width, self.height, self.Qp = width, height, Qp
+        self._vert = self._hor = None
+        self._own_ctx = ctx is None
+        self._ctx = ctx or Context(0)
+        self.timing = None
+
+    def SetBoundaryStrenght(self, vert_bs, hor_bs):
+        vert_bs = np.ascontiguousarray(vert_bs, np.uint8)
+        hor_bs = np.ascontiguousarray(hor_bs, np.uint8)
+        if vert_bs.size != num_vert_bs(self.width, self.height) or hor_bs.size != num_hor_bs(self.width, self.height):
+            raise DeblockError(_lib.ERR_BS_SIZE)              # cpu.h:122-123
+        self._vert, self._hor = vert_bs.copy(), hor_bs.copy()
+
+    def DeblockingFilter(self, num_threads=1):
+        # num_threads is the reference's OpenMP knob (cpu.h:134-135); meaningless on the GPU, accepted and ignored
+        self.timing = self._ctx.filter_frame(self.y, self.u, self.v, qp=self.Qp, vert_bs=self._vert, hor_bs=self._hor)
+
+    def Save(self, output_file_name):
+        with open(output_file_name, "wb") as fh:
+            fh.write(self.tobytes())
+
+    def tobytes(self):
+        return self.y.tobytes() + self.u.tobytes() + self.v.tobytes()
+
+    def close(self):
+        if self._own_ctx and self._ctx:
+            self._ctx.close()
+            self._ctx = None

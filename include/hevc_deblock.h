@@ -1,0 +1,193 @@
+/*
+ * hevc_deblock.h -- C ABI of the MI355X-native HEVC in-loop deblocking filter.
+ *
+ * This is the drop-in boundary for the one hot path of RomanKazantsev/gpu_video_codec:
+ * the per-frame deblocking filter that main.cu drives through ExecuteCpu / ExecuteGpu.
+ * Every entry point below names the reference interface it replaces.  Citations:
+ *   cpu.h  = hevc_deblocking_filter/hevc_deblocking_filter_cpu.h
+ *   gpu.cu = hevc_deblocking_filter/hevc_deblocking_filter_gpu.cu
+ *   main.cu = hevc_deblocking_filter/main.cu
+ *
+ * The implementation behind this header is hand-written HIP for gfx950 only.  There is no
+ * CPU fallback: every compute entry point returns HEVCDBK_ERR_HIP when no HIP device is usable.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Results are bit-exact with the
+ * reference's single-thread CPU path (cpu.h:134-993) including its quirks (SURVEY.md 8a Q-list):
+ * frames are UN-padded W x H planes here, the reference's 4-sample zero padding (cpu.h:55-71)
+ * is implicit.
+ */
+#ifndef HEVC_DEBLOCK_H
+#define HEVC_DEBLOCK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: the reference throws `const char *` at three sites; the ABI returns ---- */
+#define HEVCDBK_OK               0
+#define HEVCDBK_ERR_FILE_SIZE   (-1) /* cpu.h:43-45  / gpu.cu:1082-1084 "Incorrect file size" */
+#define HEVCDBK_ERR_DIMENSIONS  (-2) /* cpu.h:46-48  / gpu.cu:1085-1087 "Width and height of image must be multiplier of sample block size" */
+#define HEVCDBK_ERR_BS_SIZE     (-3) /* cpu.h:122-123 "Incorrect size of input boundary strenght array" */
+#define HEVCDBK_ERR_HIP         (-4) /* a HIP call failed or no device (reference prints and continues, gpu.cu:1271-1288) */
+#define HEVCDBK_ERR_ARG         (-5)
+#define HEVCDBK_ERR_NOMEM       (-6)
+#define HEVCDBK_ERR_IO          (-7)
+#define HEVCDBK_ERR_UNSUPPORTED (-8) /* alignment / bit depth outside what the kernels handle */
+
+const char *hevcdbk_strerror(int code);
+
+/* ---- context: replaces the file-scope globals of gpu.cu:37-77 (one per device, re-entrant) ---- */
+typedef struct hevcdbk_context hevcdbk_context;
+
+int hevcdbk_device_count(void);
+/* binds to HIP device `device`, creates the compute stream and the two copy side streams */
+int hevcdbk_create(int device, hevcdbk_context **ctx);
+void hevcdbk_destroy(hevcdbk_context *ctx);
+/* text of the last HIP failure seen by this context ("" if none) */
+const char *hevcdbk_last_error(const hevcdbk_context *ctx);
+/* GetGpuDeviceInfo() equivalent (main.cu:92-107): fills name, CU count, memory */
+typedef struct {
+    char name[256];
+    char gcn_arch[64];
+    int compute_units;
+    int wavefront_size;
+    int max_threads_per_block;
+    size_t total_global_mem;
+    size_t shared_mem_per_block;
+    size_t total_const_mem;
+} hevcdbk_device_info;
+int hevcdbk_get_device_info(const hevcdbk_context *ctx, hevcdbk_device_info *info);
+
+/* ---- tables and bS helpers ---- */
+/* cpu.h:1021-1033 (copies at gpu.cu:80-85, 92-97) */
+const unsigned *hevcdbk_default_tc_table(void);   /* 52 entries */
+const unsigned *hevcdbk_default_beta_table(void); /* 52 entries */
+/* cpu.h:86-87 / 104-105: element counts of the bS arrays of a plane_w x plane_h plane */
+size_t hevcdbk_num_vert_bs(unsigned plane_w, unsigned plane_h);
+size_t hevcdbk_num_hor_bs(unsigned plane_w, unsigned plane_h);
+/* cpu.h:92-99 / 110-117 (gpu.cu:1136-1180): the default "all intra" pattern, quirks included */
+int hevcdbk_default_bs(unsigned plane_w, unsigned plane_h, uint8_t *vert_bs, uint8_t *hor_bs);
+
+/* ---- operands of hevc_deblocking_filter(frame, bS, QP, tc/beta tables) ---- */
+
+/* frame: replaces ReadYuvFrame's planes (cpu.h:1041-1048) / the pinned planes of gpu.cu:37-45.
+ * Un-padded planar 4:2:0; U/V may be NULL for a luma-only call.  Caller owns the memory. */
+typedef struct {
+    unsigned width, height; /* luma samples, multiples of 8 (cpu.h:46-48); with chroma: multiples of 16 */
+    unsigned bit_depth;     /* 8..16; the reference is 8 (cpu.h:1202) */
+    unsigned sample_bytes;  /* 1 (bit_depth 8 only) or 2 (little-endian containers) */
+    void *plane[3];         /* Y, U, V */
+    size_t pitch[3];        /* bytes between rows */
+} hevcdbk_frame;
+
+/* bS: replaces SetBoundaryStrenght(vert, n, hor, n) (cpu.h:120-132).  Layouts are the reference's:
+ * vert[r*(W/8+1)+bx] = vertical edge at x = 8*bx of block row r; hor[by*(W/8)+c] = horizontal edge
+ * at y = 8*by of block column c.  NULL pointers => reference default pattern (cpu.h:92-99).
+ * The reference can only override luma; chroma overrides are an extension. */
+typedef struct {
+    const uint8_t *vert; size_t n_vert;
+    const uint8_t *hor;  size_t n_hor;
+    const uint8_t *chroma_vert; size_t n_chroma_vert;
+    const uint8_t *chroma_hor;  size_t n_chroma_hor;
+} hevcdbk_bs;
+
+/* QP: replaces the ctor's Qp (cpu.h:35-37, main.cu:117,125,133).  map != NULL selects the per-CTU
+ * map extension (BASELINE config 3b): QP of a 4-line edge segment = (QpP + QpQ + 1) >> 1 of the
+ * CTUs holding P0 / Q0 of its first line. */
+typedef struct {
+    unsigned qp;
+    const uint8_t *map;  /* map[cy*map_stride + cx], may be NULL */
+    unsigned map_stride;
+    unsigned ctu_log2;   /* CTU size in luma samples, log2 (6 => 64) */
+} hevcdbk_qp;
+
+/* tc / beta tables: replace beta_table / tc_table (cpu.h:1021-1033).  NULL => the reference's. */
+typedef struct {
+    const unsigned *tc;   /* 52 entries, each <= 255 */
+    const unsigned *beta; /* 52 entries, each <= 255 */
+} hevcdbk_tables;
+
+/* the reference's three console figures (gpu.cu:1292, 1302-1303), seconds */
+typedef struct {
+    double exec_s;  /* "Execution Time without copy on GPU"  : kernels + sync   (gpu.cu:1266-1291) */
+    double total_s; /* "Execution Time with copy on GPU"     : exec + copy      (gpu.cu:1302)      */
+    double copy_s;  /* "Copy Operation Time with GPU buffers": H2D + D2H        (gpu.cu:1246-1258, 1294-1300) */
+    double pipelined_s; /* wall time of the overlapped pinned/async pipeline actually run */
+} hevcdbk_timing;
+
+/*
+ * THE operator.  Replaces ReadYuvFrame::DeblockingFilter (cpu.h:134) and the body of ExecuteGpu
+ * (gpu.cu:1246-1300: 7 H2D copies, 3 kernel launches, sync, 3 D2H copies) for a frame in HOST
+ * memory, in place.  Staging goes through the context's pinned buffers with hipMemcpyAsync on
+ * side streams.  bs / tables / timing may be NULL.
+ */
+int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_bs *bs,
+                           const hevcdbk_qp *qp, const hevcdbk_tables *tables,
+                           hevcdbk_timing *timing);
+
+/*
+ * Device-resident form of the same operator, for callers whose planes already live in HBM
+ * (the decoder pipeline case, and what bench.py times).  One launch filters n_frames planes of
+ * identical geometry.  src and dst are DEVICE pointers and may be equal (in place); blocks are
+ * mutually independent so in-place is race-free.
+ */
+typedef struct {
+    const void *src;       /* frame f plane at src + f*frame_stride */
+    void *dst;
+    size_t pitch;          /* bytes, multiple of 4 */
+    size_t frame_stride;   /* bytes */
+    unsigned n_frames;
+    unsigned plane_w, plane_h; /* samples of THIS plane (chroma: W/2 x H/2) */
+    unsigned bit_depth, sample_bytes;
+    int is_chroma;         /* chroma block procedure: bS == 2 only, p0/q0 only (cpu.h:450-992) */
+    const uint8_t *vert_bs; /* DEVICE; frame f at vert_bs + f*vert_bs_stride (stride 0 = shared) */
+    const uint8_t *hor_bs;
+    size_t vert_bs_stride, hor_bs_stride;
+    const uint8_t *qp_map; /* DEVICE or NULL; frame f at qp_map + f*qp_map_frame_stride */
+    unsigned qp_map_stride, ctu_log2;
+    size_t qp_map_frame_stride;
+} hevcdbk_device_planes;
+
+/* kernel variant selector for hevc_deblocking_filter_device */
+#define HEVCDBK_KERNEL_AUTO    0 /* fastest kernel that supports the operands */
+#define HEVCDBK_KERNEL_GENERIC 1 /* one lane per offset block, 32-bit scalar arithmetic (all operand kinds) */
+#define HEVCDBK_KERNEL_PACKED  2 /* packed 16-bit arithmetic kernel (8-bit samples, scalar QP) */
+
+int hevc_deblocking_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes,
+                                  unsigned qp, const hevcdbk_tables *tables, int kernel_variant,
+                                  void *hip_stream /* NULL => the context's compute stream */);
+
+/* ---- device memory / stream plumbing for hosts without a HIP binding (ctypes, cgo, JNI) ---- */
+int hevcdbk_device_malloc(hevcdbk_context *ctx, size_t bytes, void **dptr);
+int hevcdbk_device_free(hevcdbk_context *ctx, void *dptr);
+int hevcdbk_host_malloc_pinned(hevcdbk_context *ctx, size_t bytes, void **hptr); /* hipHostMalloc, replaces cudaMallocHost gpu.cu:1103-1169 */
+int hevcdbk_host_free_pinned(hevcdbk_context *ctx, void *hptr);
+int hevcdbk_memcpy_h2d(hevcdbk_context *ctx, void *dptr, const void *hptr, size_t bytes); /* synchronous */
+int hevcdbk_memcpy_d2h(hevcdbk_context *ctx, void *hptr, const void *dptr, size_t bytes);
+int hevcdbk_memcpy_d2d(hevcdbk_context *ctx, void *dst, const void *src, size_t bytes);
+int hevcdbk_memset_d(hevcdbk_context *ctx, void *dptr, int value, size_t bytes);
+int hevcdbk_synchronize(hevcdbk_context *ctx); /* all three streams */
+void *hevcdbk_compute_stream(hevcdbk_context *ctx); /* hipStream_t */
+
+/* Timed replay for benchmarks: launches the device operator `steps` times back-to-back on the
+ * compute stream with a HIP event pair around EACH launch, synchronises once at the end and
+ * writes the per-launch kernel durations (milliseconds) to kernel_ms[steps]. */
+int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
+                             unsigned qp, const hevcdbk_tables *tables, int kernel_variant,
+                             unsigned steps, float *kernel_ms);
+
+/* ---- main.cu-shaped harness entry: replaces ExecuteGpu (main.cu:87-90, gpu.cu:1230-1306) ----
+ * file in -> filter Y,U,V on the GPU -> file out, printing the reference's three lines.
+ * The four launch-dimension arguments are accepted and ignored.  Returns an error code instead of
+ * throwing.  `device` selects the HIP device (the reference always uses device 0, main.cu:93). */
+int hevcdbk_execute_gpu(const char *input_file_name, const char *output_file_name,
+                        unsigned width, unsigned height, unsigned qp,
+                        unsigned dimx1, unsigned dimy1, unsigned dimx2, unsigned dimy2, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEVC_DEBLOCK_H */

@@ -1,0 +1,101 @@
+/*
+ * host_sim.cpp -- runs the KERNEL's per-block arithmetic (gpu_video_codec_amd/csrc/deblock_core.h,
+ * and deblock_packed.h when present) on the CPU over a whole plane, with the same virtual zero
+ * padding and bS guards the kernels use.  TEST-ONLY: lets the CPU test-suite compare the kernel
+ * arithmetic with the oracle bit-for-bit without a GPU.  It is not part of the product library and
+ * nothing in the product can reach it.
+ */
+#include <cstdint>
+#include <cstring>
+
+#include "../../gpu_video_codec_amd/csrc/deblock_core.h"
+#if __has_include("../../gpu_video_codec_amd/csrc/deblock_packed.h")
+#define DBK_HOST_SIM 1
+#include "../../gpu_video_codec_amd/csrc/deblock_packed.h"
+#define HAVE_PACKED 1
+#else
+#define HAVE_PACKED 0
+#endif
+
+template <typename T>
+static void load_block(const T *plane, long pitch_s, int w, int h, int bx, int by, int (&v)[8][8])
+{
+    for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++) {
+            const int x = bx * 8 - 4 + c, y = by * 8 - 4 + r;
+            v[r][c] = (x >= 0 && x < w && y >= 0 && y < h) ? plane[(long)y * pitch_s + x] : 0;
+        }
+}
+template <typename T>
+static void store_block(T *plane, long pitch_s, int w, int h, int bx, int by, const int (&v)[8][8])
+{
+    for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++) {
+            const int x = bx * 8 - 4 + c, y = by * 8 - 4 + r;
+            if (x >= 0 && x < w && y >= 0 && y < h) plane[(long)y * pitch_s + x] = (T)v[r][c];
+        }
+}
+
+template <typename T>
+static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8_t *vbs, const uint8_t *hbs,
+                int tc, int beta, int max_v, const uint8_t *map, int map_stride, int ctu_log2,
+                const uint8_t *tc_tab, const uint8_t *beta_tab, int shift, int packed)
+{
+    const int nbx = w / 8 + 1, nby = h / 8 + 1;
+    const int limit_bx = is_chroma ? 2 * w / 8 : nbx - 1, limit_by = is_chroma ? 2 * h / 8 : nby - 1;
+    const int n_vert = (w / 8 + 1) * h / 8, n_hor = (h / 8 + 1) * w / 8;
+    for (int by = 0; by < nby; by++)
+        for (int bx = 0; bx < nbx; bx++) {
+            int v[8][8];
+            load_block(plane, pitch_s, w, h, bx, by, v);
+            dbk::BlockBs bs = dbk::load_block_bs(vbs, hbs, bx, by, w / 8 + 1, w / 8, limit_bx, limit_by, n_vert, n_hor);
+            dbk::BlockQp q;
+            if (map) {
+                const int sc = is_chroma ? 2 : 1, lw = w * sc, lh = h * sc, x0 = bx * 8 - 4, y0 = by * 8 - 4;
+                const int qs[4] = {
+                    dbk::seg_qp_from_map(map, map_stride, ctu_log2, sc, lw, lh, x0 + 3, y0 + 0, x0 + 4, y0 + 0),
+                    dbk::seg_qp_from_map(map, map_stride, ctu_log2, sc, lw, lh, x0 + 3, y0 + 4, x0 + 4, y0 + 4),
+                    dbk::seg_qp_from_map(map, map_stride, ctu_log2, sc, lw, lh, x0 + 0, y0 + 3, x0 + 0, y0 + 4),
+                    dbk::seg_qp_from_map(map, map_stride, ctu_log2, sc, lw, lh, x0 + 4, y0 + 3, x0 + 0, y0 + 4)};
+                for (int s = 0; s < 4; s++) { q.tc[s] = tc_tab[qs[s]] << shift; q.beta[s] = beta_tab[qs[s]] << shift; }
+            } else {
+                for (int s = 0; s < 4; s++) { q.tc[s] = tc; q.beta[s] = beta; }
+            }
+#if HAVE_PACKED
+            if (packed) {
+                uint32_t L[8], R[8];
+                for (int r = 0; r < 8; r++) {
+                    L[r] = (uint32_t)v[r][0] | ((uint32_t)v[r][1] << 8) | ((uint32_t)v[r][2] << 16) | ((uint32_t)v[r][3] << 24);
+                    R[r] = (uint32_t)v[r][4] | ((uint32_t)v[r][5] << 8) | ((uint32_t)v[r][6] << 16) | ((uint32_t)v[r][7] << 24);
+                }
+                if (is_chroma) dbk::packed_filter_block<true>(L, R, bs, tc, beta);
+                else dbk::packed_filter_block<false>(L, R, bs, tc, beta);
+                for (int r = 0; r < 8; r++)
+                    for (int c = 0; c < 4; c++) {
+                        v[r][c] = (L[r] >> (8 * c)) & 0xff;
+                        v[r][4 + c] = (R[r] >> (8 * c)) & 0xff;
+                    }
+                store_block(plane, pitch_s, w, h, bx, by, v);
+                continue;
+            }
+#else
+            (void)packed;
+#endif
+            if (is_chroma) dbk::filter_block_generic<true>(v, bs, q, max_v);
+            else dbk::filter_block_generic<false>(v, bs, q, max_v);
+            store_block(plane, pitch_s, w, h, bx, by, v);
+        }
+}
+
+extern "C" int host_sim_have_packed(void) { return HAVE_PACKED; }
+
+extern "C" void host_sim_filter_plane(void *plane, int w, int h, long pitch_bytes, int sample_bytes, int is_chroma,
+                                      const uint8_t *vbs, const uint8_t *hbs, int tc, int beta, int max_v,
+                                      const uint8_t *map, int map_stride, int ctu_log2,
+                                      const uint8_t *tc_tab, const uint8_t *beta_tab, int shift, int packed)
+{
+    if (sample_bytes == 1)
+        run((uint8_t *)plane, w, h, pitch_bytes, is_chroma, vbs, hbs, tc, beta, max_v, map, map_stride, ctu_log2, tc_tab, beta_tab, shift, packed);
+    else
+        run((uint16_t *)plane, w, h, pitch_bytes / 2, is_chroma, vbs, hbs, tc, beta, max_v, map, map_stride, ctu_log2, tc_tab, beta_tab, shift, packed);
+}

@@ -1,0 +1,114 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol declared in
+include/hevc_deblock.h, its host-only helpers agree with the oracle, and -- with no GPU -- every
+compute entry point fails loudly instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def L():
+    from gpu_video_codec_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.lib()
+
+
+def test_exports_match_header(L):
+    from gpu_video_codec_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "hevc_deblock.h")).read()
+    declared = set(re.findall(r"\b(hevcdbk_[a-z0-9_]+|hevc_deblocking_filter(?:_device)?)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_cpp_shim_symbol_present():
+    """main.cu's forward declaration (main.cu:87-90) must resolve against the library."""
+    import subprocess
+    from gpu_video_codec_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", _lib.LIB_PATH]).decode()
+    assert "ExecuteGpu(std::" in out
+
+
+def test_no_oracle_or_cpu_filter_in_product():
+    """The product library must not link or embed the checker."""
+    import subprocess
+    from gpu_video_codec_amd import _lib
+    out = subprocess.check_output(["nm", "-D", _lib.LIB_PATH]).decode()
+    assert "dbko_" not in out and "ref_frame" not in out
+    needed = subprocess.check_output(["readelf", "-d", _lib.LIB_PATH]).decode()
+    assert "liboracle" not in needed and "libref_oracle" not in needed and "libgomp" not in needed
+    for fn in os.listdir(os.path.join(ROOT, "gpu_video_codec_amd")):
+        if fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "gpu_video_codec_amd", fn)).read()
+            assert "oracle" not in src.replace("the oracle", "").lower() or fn == "deblock.py" and "import oracle" not in src
+
+
+def test_tables_and_bs_helpers_match_oracle(L, oracle):
+    from gpu_video_codec_amd import deblock
+    tc, beta = deblock.default_tables()
+    otc, obeta = oracle.tables()
+    assert np.array_equal(tc, otc) and np.array_equal(beta, obeta)
+    for (w, h) in [(8, 8), (16, 8), (352, 288), (176, 144), (768, 576), (3840, 2160), (7680, 4320)]:
+        assert deblock.num_vert_bs(w, h) == oracle.num_vert_bs(w, h)
+        assert deblock.num_hor_bs(w, h) == oracle.num_hor_bs(w, h)
+        v, hh = deblock.default_bs(w, h)
+        ov, oh = oracle.default_bs(w, h)
+        assert np.array_equal(v, ov) and np.array_equal(hh, oh)
+    assert deblock.num_vert_bs(3840, 2160) == 129870 and deblock.num_hor_bs(3840, 2160) == 130080
+
+
+def test_error_strings_are_the_reference_messages(L):
+    from gpu_video_codec_amd import _lib
+    assert L.hevcdbk_strerror(_lib.ERR_FILE_SIZE) == b"Incorrect file size"
+    assert L.hevcdbk_strerror(_lib.ERR_DIMENSIONS) == b"Width and height of image must be multiplier of sample block size"
+    assert L.hevcdbk_strerror(_lib.ERR_BS_SIZE) == b"Incorrect size of input boundary strenght array"
+
+
+def test_fails_loudly_without_gpu(L, tmp_path):
+    """No device => HEVCDBK_ERR_HIP from create and from ExecuteGpu; never a silent CPU result."""
+    from gpu_video_codec_amd import _lib, deblock
+    if deblock.device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert L.hevcdbk_create(0, C.byref(h)) == _lib.ERR_HIP
+    with pytest.raises(deblock.DeblockError):
+        deblock.Context(0)
+    src = os.path.join(ROOT, "tests", "golden", "image1_352x288_yv12.yuv")
+    out = tmp_path / "o.yuv"
+    assert L.hevcdbk_execute_gpu(src.encode(), str(out).encode(), 352, 288, 30, 20, 20, 20, 20, 0) == _lib.ERR_HIP
+    assert not out.exists()
+
+
+def test_execute_gpu_validation_order(L, tmp_path):
+    """Size check before divisibility check, as gpu.cu:1082-1087 / cpu.h:43-48."""
+    from gpu_video_codec_amd import _lib
+    p = tmp_path / "short.yuv"
+    p.write_bytes(b"\0" * 100)
+    assert L.hevcdbk_execute_gpu(str(p).encode(), b"/dev/null", 352, 288, 30, 0, 0, 0, 0, 0) == _lib.ERR_FILE_SIZE
+    p2 = tmp_path / "odd.yuv"
+    p2.write_bytes(b"\0" * (3 * 20 * 20 // 2))
+    assert L.hevcdbk_execute_gpu(str(p2).encode(), b"/dev/null", 20, 20, 30, 0, 0, 0, 0, 0) == _lib.ERR_DIMENSIONS
+    assert L.hevcdbk_execute_gpu(b"/nonexistent.yuv", b"/dev/null", 16, 16, 30, 0, 0, 0, 0, 0) == _lib.ERR_IO
+
+
+def test_read_yuv_frame_mirror_validation(tmp_path):
+    from gpu_video_codec_amd import deblock, _lib
+    p = tmp_path / "short.yuv"
+    p.write_bytes(b"\0" * 100)
+    with pytest.raises(deblock.DeblockError) as e:
+        deblock.ReadYuvFrame(str(p), 352, 288, 30, ctx=object())
+    assert e.value.code == _lib.ERR_FILE_SIZE
+    p2 = tmp_path / "ok.yuv"
+    p2.write_bytes(b"\0" * (3 * 16 * 16 // 2))
+    f = deblock.ReadYuvFrame(str(p2), 16, 16, 30, ctx=object())
+    with pytest.raises(deblock.DeblockError) as e:
+        f.SetBoundaryStrenght(np.zeros(3, np.uint8), np.zeros(4, np.uint8))
+    assert e.value.code == _lib.ERR_BS_SIZE
