@@ -90,6 +90,16 @@ def cpu_baseline(frames, qp, bit_depth, budget_s, threads_all):
     return out
 
 
+def host_threads():
+    """Threads for the OpenMP leg: the cores this process may run on, capped at the GPU box's
+    per-GPU CPU share (16) so a 256-thread team is not time-sliced onto a handful of cores."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +110,8 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--qp", type=int, default=32)
-    ap.add_argument("--variant", choices=["auto", "generic", "packed"], default="auto")
+    ap.add_argument("--variant", choices=["auto", "generic", "packed", "copy"], default="auto",
+                    help="copy = diagnostic memory-path ablation (dst = src, no filter); never a benchmark result")
     ap.add_argument("--cpu-budget-s", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -116,7 +127,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    variant = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "packed": _lib.KERNEL_PACKED}[args.variant]
+    variant = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "packed": _lib.KERNEL_PACKED,
+               "copy": _lib.KERNEL_DIAG_COPY}[args.variant]
     w, h, F, bd = args.width, args.height, args.frames, args.bit_depth
     sb = 1 if bd == 8 else 2
     ndev = deblock.device_count()
@@ -151,7 +163,8 @@ def main():
     from oracle import oracle
     bit_exact = True
     for f in sorted({0, F // 2, F - 1}):
-        bit_exact &= bool(np.array_equal(batch.download_frame(f), oracle.filter_plane(frames[f], args.qp, bit_depth=bd)))
+        want = frames[f] if args.variant == "copy" else oracle.filter_plane(frames[f], args.qp, bit_depth=bd)
+        bit_exact &= bool(np.array_equal(batch.download_frame(f), want))
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * F * args.steps / elapsed
@@ -167,14 +180,14 @@ def main():
         "config": {"workload": "synthetic %dx%d %d-bit luma deblock, QP %d, default bS, %d frames/GPU/step, device-resident, src->dst"
                                % (w, h, bd, args.qp, F),
                    "frames_per_gpu": F, "kernel_variant": args.variant, "parallelism": "frame-parallel x%d, no collective" % world},
-        "bit_exact_vs_oracle": bit_exact,
+        "bit_exact_vs_oracle": bit_exact, "diagnostic_copy_only": args.variant == "copy",
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel_avg_ms": kavg_ms, "kernel_min_ms": float(np.min(kernel_ms)),
                      "algorithmic_bytes_per_launch": abytes,
                      "read_GBps": (abytes - w * h * sb * F) / (kavg_ms * 1e-3) / 1e9},
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.variant != "copy":
         if not args.no_e2e:
             # end-to-end (PCIe-inclusive) rate of the host-frame operator; never `value`
             yy = frames[0].copy()
@@ -188,7 +201,7 @@ def main():
             out["e2e_host_frame"] = {"frames_per_s": 1.0 / float(np.median(ts)), "exec_s": tm["exec_s"],
                                      "copy_s": tm["copy_s"], "total_s": tm["total_s"]}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames[: min(F, 8)], args.qp, bd, args.cpu_budget_s, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(frames[: min(F, 8)], args.qp, bd, args.cpu_budget_s, host_threads())
     batch.free()
     ctx.close()
     if dist is not None:

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libhevcdbk.so")
 OK, ERR_FILE_SIZE, ERR_DIMENSIONS, ERR_BS_SIZE, ERR_HIP, ERR_ARG, ERR_NOMEM, ERR_IO, ERR_UNSUPPORTED = \
     0, -1, -2, -3, -4, -5, -6, -7, -8
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED = 0, 1, 2
+KERNEL_DIAG_COPY = 100
 
 # every symbol include/hevc_deblock.h declares (tests check the library exports all of them)
 EXPORTS = [

@@ -166,13 +166,13 @@ int planes_to_args(const hevcdbk_device_planes *p, unsigned qp, const hevcdbk_ta
 int launch(hevcdbk_context *ctx, const DbkArgs &a, int sample_bytes, bool chroma, int variant, hipStream_t s)
 {
     hipError_t e;
-    if (variant == HEVCDBK_KERNEL_PACKED) {
+    if (variant == HEVCDBK_KERNEL_PACKED || variant == HEVCDBK_KERNEL_DIAG_COPY) {
         if (!dbk_packed_supports(a, sample_bytes)) return HEVCDBK_ERR_UNSUPPORTED;
-        e = dbk_launch_packed(a, chroma, s);
+        e = dbk_launch_packed(a, chroma, variant == HEVCDBK_KERNEL_DIAG_COPY ? 1 : 0, s);
     } else if (variant == HEVCDBK_KERNEL_GENERIC) {
         e = dbk_launch_generic(a, sample_bytes, chroma, s);
     } else if (variant == HEVCDBK_KERNEL_AUTO) {
-        e = dbk_packed_supports(a, sample_bytes) ? dbk_launch_packed(a, chroma, s)
+        e = dbk_packed_supports(a, sample_bytes) ? dbk_launch_packed(a, chroma, 0, s)
                                                  : dbk_launch_generic(a, sample_bytes, chroma, s);
     } else {
         return HEVCDBK_ERR_ARG;

@@ -14,6 +14,7 @@
 
 #include "deblock_core.h"
 #include "deblock_kernels.h"
+#include "deblock_packed.h"
 
 namespace {
 
@@ -134,5 +135,96 @@ hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, h
     return chroma ? launch_generic_t<uint16_t, true>(a, stream) : launch_generic_t<uint16_t, false>(a, stream);
 }
 
-bool dbk_packed_supports(const DbkArgs &, int) { return false; }
-hipError_t dbk_launch_packed(const DbkArgs &, bool, hipStream_t) { return hipErrorNotSupported; }
+/* ------------------------------------------------------------------------------------------ */
+/* packed kernel: 8-bit samples, scalar QP, v_pk_*_i16 arithmetic (deblock_packed.h)            */
+
+namespace {
+
+struct __attribute__((packed, aligned(4))) U2 {
+    uint32_t x, y;
+};
+
+/* MODE 0 = filter, MODE 1 = diagnostic copy (same loads/stores, no arithmetic: memory-path ceiling) */
+template <bool CHROMA, int MODE>
+__global__ __launch_bounds__(256) void dbk_packed_kernel(const DbkArgs a)
+{
+    /* wave-uniform coordinates: a wave = 64 consecutive bx of one block row of one frame */
+    const int by = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + threadIdx.y));
+    if (by >= a.nby) return;
+    const int f = blockIdx.z;
+    const int bx0 = blockIdx.x * 64;
+    const int bx = bx0 + (int)threadIdx.x;
+    const bool active = bx < a.nbx;
+    const bool lv = active && bx > 0;         /* cols 0..3 inside the image */
+    const bool rv = bx < a.nbx - 1;           /* cols 4..7 inside the image (implies active) */
+    const bool full = bx0 > 0 && bx0 + 64 <= a.nbx - 1; /* every lane owns both halves: one 8-byte access per row */
+    const int x0 = bx * 8 - 4, y0 = by * 8 - 4;
+
+    const uint8_t *src = a.src + (long long)f * a.frame_stride;
+    uint8_t *dst = a.dst + (long long)f * a.frame_stride;
+
+    uint32_t L[8], R[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int y = y0 + r;
+        L[r] = 0u;
+        R[r] = 0u;
+        if ((unsigned)y < (unsigned)a.plane_h) { /* wave-uniform */
+            const uint8_t *row = src + (long long)y * a.pitch;
+            if (full) {
+                const U2 w = *reinterpret_cast<const U2 *>(row + x0);
+                L[r] = w.x;
+                R[r] = w.y;
+            } else {
+                if (lv) L[r] = *reinterpret_cast<const uint32_t *>(row + x0);
+                if (rv) R[r] = *reinterpret_cast<const uint32_t *>(row + x0 + 4);
+            }
+        }
+    }
+
+    if constexpr (MODE == 0) {
+        dbk::BlockBs bs{0, 0, 0, 0};
+        if (active)
+            bs = dbk::load_block_bs(a.vert_bs + (long long)f * a.vert_bs_stride, a.hor_bs + (long long)f * a.hor_bs_stride,
+                                    bx, by, a.vstride, a.hstride, a.limit_bx, a.limit_by, a.n_vert, a.n_hor);
+        dbk::packed_filter_block<CHROMA>(L, R, bs, a.tc, a.beta);
+    }
+
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int y = y0 + r;
+        if ((unsigned)y < (unsigned)a.plane_h) {
+            uint8_t *row = dst + (long long)y * a.pitch;
+            if (full) {
+                U2 w;
+                w.x = L[r];
+                w.y = R[r];
+                *reinterpret_cast<U2 *>(row + x0) = w;
+            } else {
+                if (lv) *reinterpret_cast<uint32_t *>(row + x0) = L[r];
+                if (rv) *reinterpret_cast<uint32_t *>(row + x0 + 4) = R[r];
+            }
+        }
+    }
+}
+
+} /* namespace */
+
+bool dbk_packed_supports(const DbkArgs &a, int sample_bytes)
+{
+    return sample_bytes == 1 && a.qp_map == nullptr && a.max_v == 255;
+}
+
+hipError_t dbk_launch_packed(const DbkArgs &a, bool chroma, int mode, hipStream_t stream)
+{
+    if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
+    dim3 block(64, 4, 1);
+    dim3 grid((a.nbx + 63) / 64, (a.nby + 3) / 4, a.n_frames);
+    if (mode == 1)
+        hipLaunchKernelGGL((dbk_packed_kernel<false, 1>), grid, block, 0, stream, a);
+    else if (chroma)
+        hipLaunchKernelGGL((dbk_packed_kernel<true, 0>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((dbk_packed_kernel<false, 0>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}

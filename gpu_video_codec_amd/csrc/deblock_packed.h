@@ -1,0 +1,304 @@
+/*
+ * deblock_packed.h -- packed-int16 per-block arithmetic of the fast HIP kernel (8-bit samples).
+ *
+ * Register layout of one offset block in one lane: L[r] = cols 0..3 of row r, R[r] = cols 4..7
+ * (little-endian bytes), 16 dwords.  A segment's 4 lines are processed as two PAIRS packed in the
+ * two 16-bit halves of a VGPR so that every arithmetic instruction is a v_pk_*_i16:
+ *     pair A = lines (0,3)  -- the two lines every decision uses, so all decision
+ *                              arithmetic runs once, on pair A only
+ *     pair B = lines (1,2)
+ * Bytes <-> int16 pairs move through v_perm_b32 only (no shifts/masks): 16 perms unpack a segment,
+ * 6..16 pack it.  Every intermediate fits int16 (|9*255 + 3*255 + 8| = 3068).
+ *
+ * Algebra used (bit-exact with the reference's delta form, cpu.h:1154-1211):
+ *   (p2 + 2p1 - 6p0 + 2q0 + q1 + 4) >> 3  ==  ((p2 + 2p1 + 2p0 + 2q0 + q1 + 4) >> 3) - p0
+ * because 8*p0 is a multiple of 8 (arithmetic shift = floor).  So p0' = clamp(S0>>3, p0-c, p0+c),
+ * and since S0>>3 is a weighted mean of samples it already lies in [0,255]: the strong filter needs
+ * no final Clip2.  Same for the 4-tap (>>2) and 5-tap (>>3) sums.
+ *
+ * DBK_HOST_SIM: tests/host_sim compiles this header for the CPU with emulated primitives so the
+ * exact arithmetic below is checked against the oracle without a GPU.
+ */
+#pragma once
+#include <stdint.h>
+
+#include "deblock_core.h"
+
+namespace dbk {
+
+typedef short pk __attribute__((vector_size(4))); /* two int16 lanes in one VGPR */
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DBK_DEV 1
+#else
+#define DBK_DEV 0
+#endif
+
+DBK_HD uint32_t pk_bits(pk a) { return __builtin_bit_cast(uint32_t, a); }
+DBK_HD pk bits_pk(uint32_t a) { return __builtin_bit_cast(pk, a); }
+DBK_HD pk splat(int v) { return pk{(short)v, (short)v}; }
+
+DBK_HD pk pk_max(pk a, pk b)
+{
+#if DBK_DEV
+    return __builtin_elementwise_max(a, b); /* v_pk_max_i16 */
+#else
+    return pk{a[0] > b[0] ? a[0] : b[0], a[1] > b[1] ? a[1] : b[1]};
+#endif
+}
+DBK_HD pk pk_min(pk a, pk b)
+{
+#if DBK_DEV
+    return __builtin_elementwise_min(a, b); /* v_pk_min_i16 */
+#else
+    return pk{a[0] < b[0] ? a[0] : b[0], a[1] < b[1] ? a[1] : b[1]};
+#endif
+}
+DBK_HD pk pk_abs(pk a) { return pk_max(a, splat(0) - a); }
+DBK_HD pk pk_clamp(pk v, pk lo, pk hi) { return pk_min(pk_max(v, lo), hi); }
+/* exchange the two halves (folds into op_sel of the consuming v_pk op) */
+DBK_HD pk pk_swap(pk a) { return pk{a[1], a[0]}; }
+
+/* v_perm_b32: result byte i = selector byte i picks from {hi:lo}: 0..3 = lo bytes, 4..7 = hi bytes, 0x0c = 0x00 */
+DBK_HD uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#if DBK_DEV
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t src = ((uint64_t)hi << 32) | lo;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t s = (sel >> (8 * i)) & 0xff;
+        const uint32_t b = s <= 7 ? (uint32_t)((src >> (8 * s)) & 0xff) : 0u; /* only 0..7 and 0x0c are used here */
+        out |= b << (8 * i);
+    }
+    return out;
+#endif
+}
+
+/* the 8 taps of one line pair */
+struct Taps {
+    pk p0, p1, p2, p3, q0, q1, q2, q3;
+};
+
+/* ---- unpack ------------------------------------------------------------------------------------ */
+
+/* vertical-edge segment (cpu.h:159-284): lines are rows ra (low half) and rb (high half);
+ * P_k = col 3-k of the L dword, Q_k = col 4+k = byte k of the R dword */
+DBK_HD Taps unpack_ver(uint32_t La, uint32_t Lb, uint32_t Ra, uint32_t Rb)
+{
+    Taps t;
+    t.p0 = bits_pk(perm(Lb, La, 0x0c070c03u));
+    t.p1 = bits_pk(perm(Lb, La, 0x0c060c02u));
+    t.p2 = bits_pk(perm(Lb, La, 0x0c050c01u));
+    t.p3 = bits_pk(perm(Lb, La, 0x0c040c00u));
+    t.q0 = bits_pk(perm(Rb, Ra, 0x0c040c00u));
+    t.q1 = bits_pk(perm(Rb, Ra, 0x0c050c01u));
+    t.q2 = bits_pk(perm(Rb, Ra, 0x0c060c02u));
+    t.q3 = bits_pk(perm(Rb, Ra, 0x0c070c03u));
+    return t;
+}
+
+/* horizontal-edge segment (cpu.h:287-446): lines are columns; X holds the 4 line samples of one tap.
+ * pair A = columns (0,3), pair B = columns (1,2) */
+DBK_HD pk unpack_hor_a(uint32_t x) { return bits_pk(perm(x, x, 0x0c030c00u)); }
+DBK_HD pk unpack_hor_b(uint32_t x) { return bits_pk(perm(x, x, 0x0c020c01u)); }
+
+/* ---- decisions on pair A (cpu.h:1074-1114, 1243-1249) ------------------------------------------ */
+
+struct Decision {
+    bool filter; /* cond1 */
+    bool strong; /* cond2 && cond3 && cond4 */
+    bool cond5, cond6;
+};
+
+DBK_HD Decision decide(const Taps &a, int beta, int tc)
+{
+    const pk dp = pk_abs(a.p2 - a.p1 - a.p1 + a.p0); /* |p2 - 2p1 + p0| on lines 0 and 3 */
+    const pk dq = pk_abs(a.q2 - a.q1 - a.q1 + a.q0);
+    const pk dpq = dp + dq;
+    Decision d;
+    d.filter = (short)(dpq[0] + dpq[1]) < beta;      /* cpu.h:1086-1087 */
+    const pk e = pk_abs(a.p3 - a.p0) + pk_abs(a.q0 - a.q3); /* cpu.h:1104-1105 */
+    const pk f = pk_abs(a.p0 - a.q0);                       /* cpu.h:1109-1110 */
+    const pk m = pk_max(dpq, e);
+    const pk mm = pk_max(m, pk_swap(m));
+    const pk ff = pk_max(f, pk_swap(f));
+    d.strong = (mm[0] < (beta >> 3)) && (ff[0] < ((5 * tc) >> 1)); /* beta/8, 5*tc/2: non-negative => >> is / */
+    const int b316 = (3 * beta) >> 4;                              /* 3*beta/16 */
+    d.cond5 = (short)(dp[0] + dp[1]) < b316;
+    d.cond6 = (short)(dq[0] + dq[1]) < b316;
+    return d;
+}
+
+/* ---- filters on one line pair ------------------------------------------------------------------- */
+
+/* strong filter (cpu.h:1152-1211), c = 2*tc */
+DBK_HD void strong_pair(Taps &t, pk c)
+{
+    const pk u2 = t.p0 + t.q0 + splat(2);
+    const pk tp = u2 + t.p1;            /* p1+p0+q0+2 */
+    const pk tq = u2 + t.q1;            /* q1+q0+p0+2 */
+    const pk bp = tp + t.p2;            /* p2+p1+p0+q0+2 */
+    const pk bq = tq + t.q2;
+    const pk s0p = (tp + bp + t.q1) >> 3;                          /* (p2+2p1+2p0+2q0+q1+4)>>3 */
+    const pk s1p = bp >> 2;                                        /* (p2+p1+p0+q0+2)>>2 */
+    const pk s2p = (((t.p3 + t.p2) << 1) + bp + splat(2)) >> 3;    /* (2p3+3p2+p1+p0+q0+4)>>3 */
+    const pk s0q = (tq + bq + t.p1) >> 3;
+    const pk s1q = bq >> 2;
+    const pk s2q = (((t.q3 + t.q2) << 1) + bq + splat(2)) >> 3;
+    const pk np0 = pk_clamp(s0p, t.p0 - c, t.p0 + c);
+    const pk np1 = pk_clamp(s1p, t.p1 - c, t.p1 + c);
+    const pk np2 = pk_clamp(s2p, t.p2 - c, t.p2 + c);
+    const pk nq0 = pk_clamp(s0q, t.q0 - c, t.q0 + c);
+    const pk nq1 = pk_clamp(s1q, t.q1 - c, t.q1 + c);
+    const pk nq2 = pk_clamp(s2q, t.q2 - c, t.q2 + c);
+    t.p0 = np0; t.p1 = np1; t.p2 = np2;
+    t.q0 = nq0; t.q1 = nq1; t.q2 = nq2;
+}
+
+/* normal filter (cpu.h:1251-1354); m5 / m6 = all-ones halves where cond5 / cond6 hold */
+DBK_HD void normal_pair(Taps &t, int tc, pk m5, pk m6)
+{
+    const pk c = splat(2 * tc), c2 = splat(tc >> 1), lim = splat(10 * tc);
+    const pk zero = splat(0), maxv = splat(255);
+    const pk delta = ((t.q0 - t.p0) * splat(9) - (t.q1 - t.p1) * splat(3) + splat(8)) >> 4;
+    const pk on = (pk_abs(delta) - lim) >> 15;       /* all ones where |delta| < 10*tc (cpu.h:1254) */
+    const pk D = pk_clamp(delta, zero - c, c);
+    const pk dp1 = pk_clamp((((t.p2 + t.p0 + splat(1)) >> 1) - t.p1 + D) >> 1, zero - c2, c2);
+    const pk dq1 = pk_clamp((((t.q2 + t.q0 + splat(1)) >> 1) - t.q1 - D) >> 1, zero - c2, c2);
+    const pk Dm = D & on;
+    t.p0 = pk_clamp(t.p0 + Dm, zero, maxv);
+    t.q0 = pk_clamp(t.q0 - Dm, zero, maxv);
+    t.p1 = pk_clamp(t.p1 + (dp1 & on & m5), zero, maxv);
+    t.q1 = pk_clamp(t.q1 + (dq1 & on & m6), zero, maxv);
+}
+
+/* one luma segment given its two unpacked pairs; returns false when nothing changed */
+DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc)
+{
+    const Decision d = decide(a, beta, tc);
+    if (!d.filter) return false;
+    if (d.strong) {
+        const pk c = splat(2 * tc);
+        strong_pair(a, c);
+        strong_pair(b, c);
+    } else {
+        const pk m5 = splat(d.cond5 ? -1 : 0), m6 = splat(d.cond6 ? -1 : 0);
+        normal_pair(a, tc, m5, m6);
+        normal_pair(b, tc, m5, m6);
+    }
+    return true;
+}
+
+/* ---- segments on the register block ----------------------------------------------------------------- */
+
+/* vertical edge on rows R0..R0+3 */
+template <int R0>
+DBK_HD void luma_ver(uint32_t (&L)[8], uint32_t (&R)[8], int beta, int tc)
+{
+    Taps a = unpack_ver(L[R0], L[R0 + 3], R[R0], R[R0 + 3]);
+    Taps b = unpack_ver(L[R0 + 1], L[R0 + 2], R[R0 + 1], R[R0 + 2]);
+    if (!luma_pairs(a, b, beta, tc)) return;
+    /* pack: L row = [p3,p2,p1,p0], R row = [q0,q1,q2,q3] */
+    {
+        const uint32_t t1 = perm(pk_bits(a.p2), pk_bits(a.p3), 0x06020400u);
+        const uint32_t t2 = perm(pk_bits(a.p0), pk_bits(a.p1), 0x06020400u);
+        L[R0] = perm(t2, t1, 0x05040100u);
+        L[R0 + 3] = perm(t2, t1, 0x07060302u);
+        const uint32_t u1 = perm(pk_bits(a.q1), pk_bits(a.q0), 0x06020400u);
+        const uint32_t u2 = perm(pk_bits(a.q3), pk_bits(a.q2), 0x06020400u);
+        R[R0] = perm(u2, u1, 0x05040100u);
+        R[R0 + 3] = perm(u2, u1, 0x07060302u);
+    }
+    {
+        const uint32_t t1 = perm(pk_bits(b.p2), pk_bits(b.p3), 0x06020400u);
+        const uint32_t t2 = perm(pk_bits(b.p0), pk_bits(b.p1), 0x06020400u);
+        L[R0 + 1] = perm(t2, t1, 0x05040100u);
+        L[R0 + 2] = perm(t2, t1, 0x07060302u);
+        const uint32_t u1 = perm(pk_bits(b.q1), pk_bits(b.q0), 0x06020400u);
+        const uint32_t u2 = perm(pk_bits(b.q3), pk_bits(b.q2), 0x06020400u);
+        R[R0 + 1] = perm(u2, u1, 0x05040100u);
+        R[R0 + 2] = perm(u2, u1, 0x07060302u);
+    }
+}
+
+/* horizontal edge between rows 3|4; P taps come from PX (L for hor1, R for hor2 -- the P/Q column
+ * mismatch of cpu.h:383-387 vs 411-414), Q taps always from L rows 4..7 */
+DBK_HD void luma_hor(uint32_t (&PX)[8], uint32_t (&L)[8], int beta, int tc)
+{
+    Taps a, b;
+    a.p0 = unpack_hor_a(PX[3]); a.p1 = unpack_hor_a(PX[2]); a.p2 = unpack_hor_a(PX[1]); a.p3 = unpack_hor_a(PX[0]);
+    a.q0 = unpack_hor_a(L[4]);  a.q1 = unpack_hor_a(L[5]);  a.q2 = unpack_hor_a(L[6]);  a.q3 = unpack_hor_a(L[7]);
+    b.p0 = unpack_hor_b(PX[3]); b.p1 = unpack_hor_b(PX[2]); b.p2 = unpack_hor_b(PX[1]); b.p3 = unpack_hor_b(PX[0]);
+    b.q0 = unpack_hor_b(L[4]);  b.q1 = unpack_hor_b(L[5]);  b.q2 = unpack_hor_b(L[6]);  b.q3 = unpack_hor_b(L[7]);
+    if (!luma_pairs(a, b, beta, tc)) return;
+    /* row dword = [A.lo, B.lo, B.hi, A.hi] = columns 0,1,2,3 */
+    PX[3] = perm(pk_bits(b.p0), pk_bits(a.p0), 0x02060400u);
+    PX[2] = perm(pk_bits(b.p1), pk_bits(a.p1), 0x02060400u);
+    PX[1] = perm(pk_bits(b.p2), pk_bits(a.p2), 0x02060400u);
+    L[4] = perm(pk_bits(b.q0), pk_bits(a.q0), 0x02060400u);
+    L[5] = perm(pk_bits(b.q1), pk_bits(a.q1), 0x02060400u);
+    L[6] = perm(pk_bits(b.q2), pk_bits(a.q2), 0x02060400u);
+}
+
+/* ---- chroma (cpu.h:1431-1488): p0/q0 only, no decisions ------------------------------------------- */
+
+DBK_HD void chroma_pair(pk &p0, pk p1, pk &q0, pk q1, pk tc)
+{
+    const pk zero = splat(0), maxv = splat(255);
+    const pk dp = (((p0 - q0) << 2) + p1 - q1 + splat(4)) >> 3; /* cpu.h:1453 */
+    const pk dq = (((q0 - p0) << 2) + q1 - p1 + splat(4)) >> 3; /* cpu.h:1458 */
+    const pk np0 = pk_clamp(p0 + pk_clamp(dp, zero - tc, tc), zero, maxv);
+    const pk nq0 = pk_clamp(q0 - pk_clamp(dq, zero - tc, tc), zero, maxv);
+    p0 = np0;
+    q0 = nq0;
+}
+
+template <int R0>
+DBK_HD void chroma_ver(uint32_t (&L)[8], uint32_t (&R)[8], int tc)
+{
+    const pk c = splat(tc);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int ra = R0 + (h ? 1 : 0), rb = R0 + (h ? 2 : 3);
+        pk p0 = bits_pk(perm(L[rb], L[ra], 0x0c070c03u)), p1 = bits_pk(perm(L[rb], L[ra], 0x0c060c02u));
+        pk q0 = bits_pk(perm(R[rb], R[ra], 0x0c040c00u)), q1 = bits_pk(perm(R[rb], R[ra], 0x0c050c01u));
+        chroma_pair(p0, p1, q0, q1, c);
+        /* put p0 into byte 3 of the L rows, q0 into byte 0 of the R rows */
+        L[ra] = perm(pk_bits(p0), L[ra], 0x04020100u);
+        L[rb] = perm(pk_bits(p0), L[rb], 0x06020100u);
+        R[ra] = perm(pk_bits(q0), R[ra], 0x03020104u);
+        R[rb] = perm(pk_bits(q0), R[rb], 0x03020106u);
+    }
+}
+
+DBK_HD void chroma_hor(uint32_t (&PX)[8], uint32_t (&L)[8], int tc)
+{
+    const pk c = splat(tc);
+    pk ap0 = unpack_hor_a(PX[3]), ap1 = unpack_hor_a(PX[2]), aq0 = unpack_hor_a(L[4]), aq1 = unpack_hor_a(L[5]);
+    pk bp0 = unpack_hor_b(PX[3]), bp1 = unpack_hor_b(PX[2]), bq0 = unpack_hor_b(L[4]), bq1 = unpack_hor_b(L[5]);
+    chroma_pair(ap0, ap1, aq0, aq1, c);
+    chroma_pair(bp0, bp1, bq0, bq1, c);
+    PX[3] = perm(pk_bits(bp0), pk_bits(ap0), 0x02060400u);
+    L[4] = perm(pk_bits(bq0), pk_bits(aq0), 0x02060400u);
+}
+
+/* ---- the whole block: ver1 -> ver2 -> hor1 -> hor2 --------------------------------------- */
+template <bool CHROMA>
+DBK_HD void packed_filter_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, int tc, int beta)
+{
+    if constexpr (CHROMA) {
+        if (bs.ver1 == 2) chroma_ver<0>(L, R, tc);
+        if (bs.ver2 == 2) chroma_ver<4>(L, R, tc);
+        if (bs.hor1 == 2) chroma_hor(L, L, tc);
+        if (bs.hor2 == 2) chroma_hor(R, L, tc);
+    } else {
+        if (bs.ver1 > 0) luma_ver<0>(L, R, beta, tc);
+        if (bs.ver2 > 0) luma_ver<4>(L, R, beta, tc);
+        if (bs.hor1 > 0) luma_hor(L, L, beta, tc);
+        if (bs.hor2 > 0) luma_hor(R, L, beta, tc);
+    }
+}
+
+} /* namespace dbk */

@@ -208,9 +208,13 @@ def test_4k_batch_properties(ctx, oracle):
         assert np.array_equal(single[0], got[2])
         assert np.array_equal(run_batch(ctx, frames[:1], 17, variant=variant)[0], base)
         assert np.array_equal(run_batch(ctx, frames[:1], 99, variant=variant), run_batch(ctx, frames[:1], 51, variant=variant))
-        # circular shift by whole 8x8 blocks commutes with the filter away from the frame border
-        sh = run_batch(ctx, frames[1:2], 32, variant=variant)[0]
-        assert np.array_equal(sh[16:-16, 24:-24], np.roll(got[0], (8, 16), (0, 1))[16:-16, 24:-24])
+        # with a position-independent bS (all 2; the default pattern has the Q3 zeros) a circular shift
+        # by whole 8x8 blocks commutes with the filter away from the frame border and the wrap seam
+        vb2 = np.full(oracle.num_vert_bs(3840, 2160), 2, np.uint8)
+        hb2 = np.full(oracle.num_hor_bs(3840, 2160), 2, np.uint8)
+        a0 = run_batch(ctx, frames[0:1], 32, variant=variant, bs=[(vb2, hb2)])[0]
+        sh = run_batch(ctx, frames[1:2], 32, variant=variant, bs=[(vb2, hb2)])[0]
+        assert np.array_equal(sh[16:-16, 24:-24], np.roll(a0, (8, 16), (0, 1))[16:-16, 24:-24])
 
 
 def test_8k_10bit_frame(ctx, oracle):
