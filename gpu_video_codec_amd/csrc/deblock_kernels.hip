@@ -12,6 +12,9 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "deblock_core.h"
 #include "deblock_kernels.h"
 #include "deblock_packed.h"
@@ -140,72 +143,110 @@ hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, h
 
 namespace {
 
-struct __attribute__((packed, aligned(4))) U2 {
-    uint32_t x, y;
-};
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-/* MODE 0 = filter, MODE 1 = diagnostic copy (same loads/stores, no arithmetic: memory-path ceiling) */
-template <bool CHROMA, int MODE>
-__global__ __launch_bounds__(256) void dbk_packed_kernel(const DbkArgs a)
+/* cache-policy bits of the raw buffer builtins on gfx950: bit 1 = nt (streamed, evict first) */
+template <bool NT> constexpr int aux_bits() { return NT ? 2 : 0; }
+constexpr uint32_t kOob = 0xfffffff0u; /* voffset >= num_records: load returns 0, store is dropped */
+
+/*
+ * Body of the packed kernel for one lane (= one offset block).
+ *
+ * EDGE == false: interior wave -- all 64 lanes own both halves of all 8 rows.  The 8 row loads are
+ *   8 back-to-back buffer_load_dwordx2 with a scalar row offset (no per-row branch, no VALU address
+ *   math), so a wave has its whole 4 KB tile in flight before the first s_waitcnt.
+ * EDGE == true: frame-edge wave (first/last block row, first/last wave of a row).  Out-of-image
+ *   halves use an out-of-range buffer offset: the hardware returns 0 for the load (= the
+ *   reference's zero padding, cpu.h:55-71) and drops the store.  Out-of-image rows are skipped
+ *   with wave-uniform branches.
+ * MODE 0 = filter, MODE 1 = diagnostic copy (same loads/stores, no arithmetic).
+ */
+template <bool CHROMA, int MODE, bool NT, bool EDGE>
+__device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int bx)
 {
-    /* wave-uniform coordinates: a wave = 64 consecutive bx of one block row of one frame */
-    const int by = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + threadIdx.y));
-    if (by >= a.nby) return;
-    const int f = blockIdx.z;
-    const int bx0 = blockIdx.x * 64;
-    const int bx = bx0 + (int)threadIdx.x;
     const bool active = bx < a.nbx;
-    const bool lv = active && bx > 0;         /* cols 0..3 inside the image */
-    const bool rv = bx < a.nbx - 1;           /* cols 4..7 inside the image (implies active) */
-    const bool full = bx0 > 0 && bx0 + 64 <= a.nbx - 1; /* every lane owns both halves: one 8-byte access per row */
-    const int x0 = bx * 8 - 4, y0 = by * 8 - 4;
+    const bool lv = active && bx > 0;   /* cols 0..3 inside the image */
+    const bool rv = bx < a.nbx - 1;     /* cols 4..7 inside the image (implies active) */
+    const int y0 = by * 8 - 4;
+    const uint32_t xoff = (uint32_t)(bx * 8 - 4);
+    const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
 
-    const uint8_t *src = a.src + (long long)f * a.frame_stride;
-    uint8_t *dst = a.dst + (long long)f * a.frame_stride;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.src) + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        a.dst + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
 
     uint32_t L[8], R[8];
+    if constexpr (!EDGE) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int y = y0 + r;
-        L[r] = 0u;
-        R[r] = 0u;
-        if ((unsigned)y < (unsigned)a.plane_h) { /* wave-uniform */
-            const uint8_t *row = src + (long long)y * a.pitch;
-            if (full) {
-                const U2 w = *reinterpret_cast<const U2 *>(row + x0);
-                L[r] = w.x;
-                R[r] = w.y;
-            } else {
-                if (lv) L[r] = *reinterpret_cast<const uint32_t *>(row + x0);
-                if (rv) R[r] = *reinterpret_cast<const uint32_t *>(row + x0 + 4);
+        for (int r = 0; r < 8; r++) {
+            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
+            L[r] = w.x;
+            R[r] = w.y;
+        }
+    } else {
+        const uint32_t lo = lv ? xoff : kOob, ro = rv ? xoff + 4u : kOob;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int y = y0 + r;
+            L[r] = 0u;
+            R[r] = 0u;
+            if ((unsigned)y < (unsigned)a.plane_h) { /* wave-uniform */
+                L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, lo, y * (int)a.pitch, aux_bits<NT>());
+                R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, ro, y * (int)a.pitch, aux_bits<NT>());
             }
         }
     }
 
     if constexpr (MODE == 0) {
         dbk::BlockBs bs{0, 0, 0, 0};
-        if (active)
+        if (!EDGE || active)
             bs = dbk::load_block_bs(a.vert_bs + (long long)f * a.vert_bs_stride, a.hor_bs + (long long)f * a.hor_bs_stride,
                                     bx, by, a.vstride, a.hstride, a.limit_bx, a.limit_by, a.n_vert, a.n_hor);
         dbk::packed_filter_block<CHROMA>(L, R, bs, a.tc, a.beta);
     }
 
+    if constexpr (!EDGE) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int y = y0 + r;
-        if ((unsigned)y < (unsigned)a.plane_h) {
-            uint8_t *row = dst + (long long)y * a.pitch;
-            if (full) {
-                U2 w;
-                w.x = L[r];
-                w.y = R[r];
-                *reinterpret_cast<U2 *>(row + x0) = w;
-            } else {
-                if (lv) *reinterpret_cast<uint32_t *>(row + x0) = L[r];
-                if (rv) *reinterpret_cast<uint32_t *>(row + x0 + 4) = R[r];
+        for (int r = 0; r < 8; r++) {
+            u32x2 w;
+            w.x = L[r];
+            w.y = R[r];
+            __builtin_amdgcn_raw_buffer_store_b64(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
+        }
+    } else {
+        const uint32_t lo = lv ? xoff : kOob, ro = rv ? xoff + 4u : kOob;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int y = y0 + r;
+            if ((unsigned)y < (unsigned)a.plane_h) {
+                __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, lo, y * (int)a.pitch, aux_bits<NT>());
+                __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, ro, y * (int)a.pitch, aux_bits<NT>());
             }
         }
     }
+}
+
+/*
+ * Work mapping: ONE WORKGROUP OWNS ONE BLOCK ROW of one frame (up to 1024 offset blocks per
+ * workgroup; wider planes take blockIdx.z chunks).  A wave is 64 consecutive bx, so each of its
+ * row accesses is one contiguous 512-byte span that starts 4 bytes before an 8-byte boundary
+ * (offset blocks start at image x = 8*bx - 4).  The 128-byte lines at both ends of a wave's span
+ * are shared with the neighbouring wave; keeping all waves of a block row in one workgroup keeps
+ * both halves of every such line on one CU / one XCD L2, where the partial writes merge before
+ * write-back.
+ */
+template <bool CHROMA, int MODE, bool NT>
+__global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
+{
+    const int by = blockIdx.x; /* scalar */
+    const int f = blockIdx.y;  /* scalar */
+    const int bx = blockIdx.z * 1024 + (int)threadIdx.x;
+    const int wave_bx0 = __builtin_amdgcn_readfirstlane(bx) & ~63;
+    /* wave-uniform: every lane owns both halves of all 8 rows */
+    const bool interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && by > 0 && by < a.nby - 1;
+    if (interior) packed_body<CHROMA, MODE, NT, false>(a, by, f, bx);
+    else packed_body<CHROMA, MODE, NT, true>(a, by, f, bx);
 }
 
 } /* namespace */
@@ -215,16 +256,31 @@ bool dbk_packed_supports(const DbkArgs &a, int sample_bytes)
     return sample_bytes == 1 && a.qp_map == nullptr && a.max_v == 255;
 }
 
+/* development knob: HEVCDBK_TUNE=nt selects the non-temporal variant (A/B runs in bench.py) */
+static bool tune_nt()
+{
+    static const bool v = [] { const char *e = getenv("HEVCDBK_TUNE"); return e && strstr(e, "nt") != nullptr; }();
+    return v;
+}
+
+template <bool NT>
+static void launch_packed_t(const DbkArgs &a, bool chroma, int mode, dim3 grid, dim3 block, hipStream_t stream)
+{
+    if (mode == 1)
+        hipLaunchKernelGGL((dbk_packed_kernel<false, 1, NT>), grid, block, 0, stream, a);
+    else if (chroma)
+        hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((dbk_packed_kernel<false, 0, NT>), grid, block, 0, stream, a);
+}
+
 hipError_t dbk_launch_packed(const DbkArgs &a, bool chroma, int mode, hipStream_t stream)
 {
     if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
-    dim3 block(64, 4, 1);
-    dim3 grid((a.nbx + 63) / 64, (a.nby + 3) / 4, a.n_frames);
-    if (mode == 1)
-        hipLaunchKernelGGL((dbk_packed_kernel<false, 1>), grid, block, 0, stream, a);
-    else if (chroma)
-        hipLaunchKernelGGL((dbk_packed_kernel<true, 0>), grid, block, 0, stream, a);
-    else
-        hipLaunchKernelGGL((dbk_packed_kernel<false, 0>), grid, block, 0, stream, a);
+    const int per_wg = a.nbx < 1024 ? a.nbx : 1024;
+    dim3 block((per_wg + 63) / 64 * 64, 1, 1);            /* whole waves; one block row per workgroup */
+    dim3 grid(a.nby, a.n_frames, (a.nbx + 1023) / 1024);
+    if (tune_nt()) launch_packed_t<true>(a, chroma, mode, grid, block, stream);
+    else launch_packed_t<false>(a, chroma, mode, grid, block, stream);
     return hipGetLastError();
 }
