@@ -241,7 +241,7 @@ __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
 {
     const int by = blockIdx.x; /* scalar */
     const int f = blockIdx.y;  /* scalar */
-    const int bx = blockIdx.z * 1024 + (int)threadIdx.x;
+    const int bx = blockIdx.z * (int)blockDim.x + (int)threadIdx.x;
     const int wave_bx0 = __builtin_amdgcn_readfirstlane(bx) & ~63;
     /* wave-uniform: every lane owns both halves of all 8 rows */
     const bool interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && by > 0 && by < a.nby - 1;
@@ -277,9 +277,11 @@ static void launch_packed_t(const DbkArgs &a, bool chroma, int mode, dim3 grid, 
 hipError_t dbk_launch_packed(const DbkArgs &a, bool chroma, int mode, hipStream_t stream)
 {
     if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
-    const int per_wg = a.nbx < 1024 ? a.nbx : 1024;
+    int cap = 1024;
+    if (const char *e = getenv("HEVCDBK_WG")) cap = atoi(e) >= 64 ? (atoi(e) / 64 * 64 > 1024 ? 1024 : atoi(e) / 64 * 64) : 1024;
+    const int per_wg = a.nbx < cap ? a.nbx : cap;
     dim3 block((per_wg + 63) / 64 * 64, 1, 1);            /* whole waves; one block row per workgroup */
-    dim3 grid(a.nby, a.n_frames, (a.nbx + 1023) / 1024);
+    dim3 grid(a.nby, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
     if (tune_nt()) launch_packed_t<true>(a, chroma, mode, grid, block, stream);
     else launch_packed_t<false>(a, chroma, mode, grid, block, stream);
     return hipGetLastError();
