@@ -185,16 +185,15 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             R[r] = w.y;
         }
     } else {
+        /* straight-line: an out-of-image half or row gets an out-of-range offset (load -> 0) */
         const uint32_t lo = lv ? xoff : kOob, ro = rv ? xoff + 4u : kOob;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int y = y0 + r;
-            L[r] = 0u;
-            R[r] = 0u;
-            if ((unsigned)y < (unsigned)a.plane_h) { /* wave-uniform */
-                L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, lo, y * (int)a.pitch, aux_bits<NT>());
-                R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, ro, y * (int)a.pitch, aux_bits<NT>());
-            }
+            const bool yv = (unsigned)y < (unsigned)a.plane_h; /* wave-uniform */
+            const int soff = yv ? y * (int)a.pitch : 0;
+            L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, yv ? lo : kOob, soff, aux_bits<NT>());
+            R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, yv ? ro : kOob, soff, aux_bits<NT>());
         }
     }
 
@@ -219,10 +218,10 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int y = y0 + r;
-            if ((unsigned)y < (unsigned)a.plane_h) {
-                __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, lo, y * (int)a.pitch, aux_bits<NT>());
-                __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, ro, y * (int)a.pitch, aux_bits<NT>());
-            }
+            const bool yv = (unsigned)y < (unsigned)a.plane_h;
+            const int soff = yv ? y * (int)a.pitch : 0;
+            __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, yv ? lo : kOob, soff, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, yv ? ro : kOob, soff, aux_bits<NT>());
         }
     }
 }

@@ -55,6 +55,18 @@ DBK_HD pk pk_min(pk a, pk b)
 #endif
 }
 DBK_HD pk pk_abs(pk a) { return pk_max(a, splat(0) - a); }
+
+/*
+ * Carry-free SWAR forms.  On gfx950 the packed v_pk_add/sub_u16 issue at 4 cycles per wave64 while a
+ * plain v_add_u32 / v_sub_u32 issues at 2 (measured, tools/ubench/valu_rate*.hip).  When both 16-bit
+ * fields are known non-negative and the field results stay inside [0, 65535] no carry or borrow can
+ * cross the field boundary, so a 32-bit add / sub of the two packed registers IS the packed result.
+ */
+DBK_HD pk uadd(pk a, pk b) { return bits_pk(pk_bits(a) + pk_bits(b)); }  /* fields >= 0, sums < 65536 */
+DBK_HD pk usub(pk a, pk b) { return bits_pk(pk_bits(a) - pk_bits(b)); }  /* field-wise a >= b >= 0 */
+DBK_HD pk uaddc(pk a, uint32_t c2) { return bits_pk(pk_bits(a) + c2); }  /* c2 = constant in both fields */
+/* |a - b| of non-negative fields without a signed negate: max - min */
+DBK_HD pk absdiff(pk a, pk b) { return usub(pk_max(a, b), pk_min(a, b)); }
 DBK_HD pk pk_clamp(pk v, pk lo, pk hi) { return pk_min(pk_max(v, lo), hi); }
 /* exchange the two halves (folds into op_sel of the consuming v_pk op) */
 DBK_HD pk pk_swap(pk a) { return pk{a[1], a[0]}; }
@@ -114,13 +126,13 @@ struct Decision {
 
 DBK_HD Decision decide(const Taps &a, int beta, int tc)
 {
-    const pk dp = pk_abs(a.p2 - a.p1 - a.p1 + a.p0); /* |p2 - 2p1 + p0| on lines 0 and 3 */
-    const pk dq = pk_abs(a.q2 - a.q1 - a.q1 + a.q0);
-    const pk dpq = dp + dq;
+    const pk dp = absdiff(uadd(a.p2, a.p0), uadd(a.p1, a.p1)); /* |p2 - 2p1 + p0| on lines 0 and 3 */
+    const pk dq = absdiff(uadd(a.q2, a.q0), uadd(a.q1, a.q1));
+    const pk dpq = uadd(dp, dq);
     Decision d;
     d.filter = (short)(dpq[0] + dpq[1]) < beta;      /* cpu.h:1086-1087 */
-    const pk e = pk_abs(a.p3 - a.p0) + pk_abs(a.q0 - a.q3); /* cpu.h:1104-1105 */
-    const pk f = pk_abs(a.p0 - a.q0);                       /* cpu.h:1109-1110 */
+    const pk e = uadd(absdiff(a.p3, a.p0), absdiff(a.q0, a.q3)); /* cpu.h:1104-1105 */
+    const pk f = absdiff(a.p0, a.q0);                            /* cpu.h:1109-1110 */
     const pk m = pk_max(dpq, e);
     const pk mm = pk_max(m, pk_swap(m));
     const pk ff = pk_max(f, pk_swap(f));
@@ -136,23 +148,25 @@ DBK_HD Decision decide(const Taps &a, int beta, int tc)
 /* strong filter (cpu.h:1152-1211), c = 2*tc */
 DBK_HD void strong_pair(Taps &t, pk c)
 {
-    const pk u2 = t.p0 + t.q0 + splat(2);
-    const pk tp = u2 + t.p1;            /* p1+p0+q0+2 */
-    const pk tq = u2 + t.q1;            /* q1+q0+p0+2 */
-    const pk bp = tp + t.p2;            /* p2+p1+p0+q0+2 */
-    const pk bq = tq + t.q2;
-    const pk s0p = (tp + bp + t.q1) >> 3;                          /* (p2+2p1+2p0+2q0+q1+4)>>3 */
-    const pk s1p = bp >> 2;                                        /* (p2+p1+p0+q0+2)>>2 */
-    const pk s2p = (((t.p3 + t.p2) << 1) + bp + splat(2)) >> 3;    /* (2p3+3p2+p1+p0+q0+4)>>3 */
-    const pk s0q = (tq + bq + t.p1) >> 3;
+    /* every partial sum is a sum of samples (<= 8*255+4): carry-free 32-bit adds */
+    const pk u2 = uaddc(uadd(t.p0, t.q0), 0x00020002u);
+    const pk tp = uadd(u2, t.p1);       /* p1+p0+q0+2 */
+    const pk tq = uadd(u2, t.q1);       /* q1+q0+p0+2 */
+    const pk bp = uadd(tp, t.p2);       /* p2+p1+p0+q0+2 */
+    const pk bq = uadd(tq, t.q2);
+    const pk p32 = uadd(t.p3, t.p2), q32 = uadd(t.q3, t.q2);
+    const pk s0p = uadd(uadd(tp, bp), t.q1) >> 3;                         /* (p2+2p1+2p0+2q0+q1+4)>>3 */
+    const pk s1p = bp >> 2;                                               /* (p2+p1+p0+q0+2)>>2 */
+    const pk s2p = uaddc(uadd(uadd(p32, p32), bp), 0x00020002u) >> 3;     /* (2p3+3p2+p1+p0+q0+4)>>3 */
+    const pk s0q = uadd(uadd(tq, bq), t.p1) >> 3;
     const pk s1q = bq >> 2;
-    const pk s2q = (((t.q3 + t.q2) << 1) + bq + splat(2)) >> 3;
-    const pk np0 = pk_clamp(s0p, t.p0 - c, t.p0 + c);
-    const pk np1 = pk_clamp(s1p, t.p1 - c, t.p1 + c);
-    const pk np2 = pk_clamp(s2p, t.p2 - c, t.p2 + c);
-    const pk nq0 = pk_clamp(s0q, t.q0 - c, t.q0 + c);
-    const pk nq1 = pk_clamp(s1q, t.q1 - c, t.q1 + c);
-    const pk nq2 = pk_clamp(s2q, t.q2 - c, t.q2 + c);
+    const pk s2q = uaddc(uadd(uadd(q32, q32), bq), 0x00020002u) >> 3;
+    const pk np0 = pk_clamp(s0p, t.p0 - c, uadd(t.p0, c));
+    const pk np1 = pk_clamp(s1p, t.p1 - c, uadd(t.p1, c));
+    const pk np2 = pk_clamp(s2p, t.p2 - c, uadd(t.p2, c));
+    const pk nq0 = pk_clamp(s0q, t.q0 - c, uadd(t.q0, c));
+    const pk nq1 = pk_clamp(s1q, t.q1 - c, uadd(t.q1, c));
+    const pk nq2 = pk_clamp(s2q, t.q2 - c, uadd(t.q2, c));
     t.p0 = np0; t.p1 = np1; t.p2 = np2;
     t.q0 = nq0; t.q1 = nq1; t.q2 = nq2;
 }
@@ -165,8 +179,10 @@ DBK_HD void normal_pair(Taps &t, int tc, pk m5, pk m6)
     const pk delta = ((t.q0 - t.p0) * splat(9) - (t.q1 - t.p1) * splat(3) + splat(8)) >> 4;
     const pk on = (pk_abs(delta) - lim) >> 15;       /* all ones where |delta| < 10*tc (cpu.h:1254) */
     const pk D = pk_clamp(delta, zero - c, c);
-    const pk dp1 = pk_clamp((((t.p2 + t.p0 + splat(1)) >> 1) - t.p1 + D) >> 1, zero - c2, c2);
-    const pk dq1 = pk_clamp((((t.q2 + t.q0 + splat(1)) >> 1) - t.q1 - D) >> 1, zero - c2, c2);
+    const pk ap = uaddc(uadd(t.p2, t.p0), 0x00010001u) >> 1; /* (p2+p0+1)>>1, non-negative */
+    const pk aq = uaddc(uadd(t.q2, t.q0), 0x00010001u) >> 1;
+    const pk dp1 = pk_clamp((ap - t.p1 + D) >> 1, zero - c2, c2);
+    const pk dq1 = pk_clamp((aq - t.q1 - D) >> 1, zero - c2, c2);
     const pk Dm = D & on;
     t.p0 = pk_clamp(t.p0 + Dm, zero, maxv);
     t.q0 = pk_clamp(t.q0 - Dm, zero, maxv);
