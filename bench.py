@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 # load the product library (and with it /opt/rocm's HIP runtime) BEFORE torch is imported
-from gpu_video_codec_amd import _lib, deblock, synth  # noqa: E402
+from gpu_video_codec_amd import _lib, deblock, shard, synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -90,6 +90,24 @@ def cpu_baseline(frames, qp, bit_depth, budget_s, threads_all):
     return out
 
 
+def measured_traffic(w, h, F, bd):
+    """HBM bytes per launch from the PMC counters (tools/hbm_traffic.py: separate FETCH_SIZE / WRITE_SIZE
+    passes, calibrated on the diagnostic copy variant), taken from the newest committed
+    profiles/*_hbm_traffic.json whose workload matches this run; None otherwise."""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+        try:
+            with open(fn) as fh:
+                t = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        wl = t.get("workload", {})
+        if (wl.get("width"), wl.get("height"), wl.get("frames_per_launch"), wl.get("bit_depth")) == (w, h, F, bd):
+            best = (t["hbm_bytes_per_launch"], os.path.basename(fn))
+    return best
+
+
 def host_threads():
     """Threads for the OpenMP leg: the cores this process may run on, capped at the GPU box's
     per-GPU CPU share (16) so a 256-thread team is not time-sliced onto a handful of cores."""
@@ -153,11 +171,7 @@ def main():
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(dist, elapsed)  # MAX over ranks (gloo; control plane only)
 
     # parity spot check on what the timed launches wrote (not timed)
     from oracle import oracle
@@ -172,6 +186,7 @@ def main():
     kavg_ms = float(np.mean(kernel_ms))
     achieved = abytes / (kavg_ms * 1e-3) / 1e9
 
+    traffic = measured_traffic(w, h, F, bd) if args.variant in ("auto", "packed") else None
     out = {
         "metric": "luma_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -182,7 +197,8 @@ def main():
                    "frames_per_gpu": F, "kernel_variant": args.variant, "parallelism": "frame-parallel x%d, no collective" % world},
         "bit_exact_vs_oracle": bit_exact, "diagnostic_copy_only": args.variant == "copy",
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic[0] if traffic else None,
+                     "traffic_source": traffic[1] if traffic else None,
                      "kernel_avg_ms": kavg_ms, "kernel_min_ms": float(np.min(kernel_ms)),
                      "algorithmic_bytes_per_launch": abytes,
                      "read_GBps": (abytes - w * h * sb * F) / (kavg_ms * 1e-3) / 1e9},
