@@ -67,6 +67,37 @@ DBK_HD pk usub(pk a, pk b) { return bits_pk(pk_bits(a) - pk_bits(b)); }  /* fiel
 DBK_HD pk uaddc(pk a, uint32_t c2) { return bits_pk(pk_bits(a) + c2); }  /* c2 = constant in both fields */
 /* |a - b| of non-negative fields without a signed negate: max - min */
 DBK_HD pk absdiff(pk a, pk b) { return usub(pk_max(a, b), pk_min(a, b)); }
+/* a*K + c and a*K + C in ONE v_pk_mad_i16 (K, C small compile-time constants = inline operands).
+ * hipcc canonicalises x*2 into a shift and splits mul/add, so the instruction is written out. */
+template <int K>
+DBK_HD pk mad_k(pk a, pk c)
+{
+#if DBK_DEV
+    pk d;
+    asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "n"(K), "v"(c));
+    return d;
+#else
+    return a * splat(K) + c;
+#endif
+}
+template <int K, int C>
+DBK_HD pk mad_kc(pk a)
+{
+#if DBK_DEV
+    pk d;
+    asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "n"(K), "n"(C));
+    return d;
+#else
+    return a * splat(K) + splat(C);
+#endif
+}
+
+/* low half + high half of non-negative fields, as a 16-bit unsigned value */
+DBK_HD unsigned lohi_sum(pk a)
+{
+    const uint32_t x = pk_bits(a);
+    return (uint16_t)(x + (x >> 16));
+}
 DBK_HD pk pk_clamp(pk v, pk lo, pk hi) { return pk_min(pk_max(v, lo), hi); }
 /* exchange the two halves (folds into op_sel of the consuming v_pk op) */
 DBK_HD pk pk_swap(pk a) { return pk{a[1], a[0]}; }
@@ -130,16 +161,20 @@ DBK_HD Decision decide(const Taps &a, int beta, int tc)
     const pk dq = absdiff(uadd(a.q2, a.q0), uadd(a.q1, a.q1));
     const pk dpq = uadd(dp, dq);
     Decision d;
-    d.filter = (short)(dpq[0] + dpq[1]) < beta;      /* cpu.h:1086-1087 */
+    /* sum of the two halves in the low 16 bits: x + (x >> 16), compared as a 16-bit value */
+    d.filter = lohi_sum(dpq) < (unsigned)beta;                  /* cpu.h:1086-1087 */
     const pk e = uadd(absdiff(a.p3, a.p0), absdiff(a.q0, a.q3)); /* cpu.h:1104-1105 */
     const pk f = absdiff(a.p0, a.q0);                            /* cpu.h:1109-1110 */
     const pk m = pk_max(dpq, e);
-    const pk mm = pk_max(m, pk_swap(m));
-    const pk ff = pk_max(f, pk_swap(f));
-    d.strong = (mm[0] < (beta >> 3)) && (ff[0] < ((5 * tc) >> 1)); /* beta/8, 5*tc/2: non-negative => >> is / */
-    const int b316 = (3 * beta) >> 4;                              /* 3*beta/16 */
-    d.cond5 = (short)(dp[0] + dp[1]) < b316;
-    d.cond6 = (short)(dq[0] + dq[1]) < b316;
+    /* "both halves < T" without extracting them: (0x8000|T-1) - x keeps bit 15 of a half iff x < T */
+    const int b8 = beta >> 3, tc52 = (5 * tc) >> 1;              /* beta/8, 5*tc/2: non-negative => >> is / */
+    const uint32_t k1 = 0x80008000u | ((uint32_t)(b8 - 1) * 0x00010001u);
+    const uint32_t k2 = 0x80008000u | ((uint32_t)(tc52 - 1) * 0x00010001u);
+    const uint32_t ok = (k1 - pk_bits(m)) & (k2 - pk_bits(f)) & 0x80008000u;
+    d.strong = b8 > 0 && tc52 > 0 && ok == 0x80008000u;
+    const unsigned b316 = (unsigned)((3 * beta) >> 4);          /* 3*beta/16 */
+    d.cond5 = lohi_sum(dp) < b316;
+    d.cond6 = lohi_sum(dq) < b316;
     return d;
 }
 
@@ -176,13 +211,16 @@ DBK_HD void normal_pair(Taps &t, int tc, pk m5, pk m6)
 {
     const pk c = splat(2 * tc), c2 = splat(tc >> 1), lim = splat(10 * tc);
     const pk zero = splat(0), maxv = splat(255);
-    const pk delta = ((t.q0 - t.p0) * splat(9) - (t.q1 - t.p1) * splat(3) + splat(8)) >> 4;
+    /* (9(q0-p0) - 3(q1-p1) + 8) >> 4 as two multiply-adds (v_pk_mad_i16) */
+    const pk delta = mad_k<9>(t.q0 - t.p0, mad_kc<-3, 8>(t.q1 - t.p1)) >> 4;
     const pk on = (pk_abs(delta) - lim) >> 15;       /* all ones where |delta| < 10*tc (cpu.h:1254) */
     const pk D = pk_clamp(delta, zero - c, c);
-    const pk ap = uaddc(uadd(t.p2, t.p0), 0x00010001u) >> 1; /* (p2+p0+1)>>1, non-negative */
-    const pk aq = uaddc(uadd(t.q2, t.q0), 0x00010001u) >> 1;
-    const pk dp1 = pk_clamp((ap - t.p1 + D) >> 1, zero - c2, c2);
-    const pk dq1 = pk_clamp((aq - t.q1 - D) >> 1, zero - c2, c2);
+    /* (((p2+p0+1)>>1) - p1 + D) >> 1  ==  (p2 + p0 + 1 - 2*p1 + 2*D) >> 2   (floor of a floor: the dropped
+     * bit of the inner shift is worth 1/4 and cannot carry across an integer) */
+    const pk xp = uaddc(uadd(t.p2, t.p0), 0x00010001u);
+    const pk xq = uaddc(uadd(t.q2, t.q0), 0x00010001u);
+    const pk dp1 = pk_clamp(mad_k<2>(D, mad_k<-2>(t.p1, xp)) >> 2, zero - c2, c2);
+    const pk dq1 = pk_clamp(mad_k<-2>(D, mad_k<-2>(t.q1, xq)) >> 2, zero - c2, c2);
     const pk Dm = D & on;
     t.p0 = pk_clamp(t.p0 + Dm, zero, maxv);
     t.q0 = pk_clamp(t.q0 - Dm, zero, maxv);
@@ -300,6 +338,68 @@ DBK_HD void chroma_hor(uint32_t (&PX)[8], uint32_t (&L)[8], int tc)
     L[4] = perm(pk_bits(bq0), pk_bits(aq0), 0x02060400u);
 }
 
+/* ---- luma block with the int16 pairs kept across ver -> hor ------------------------------------------
+ *
+ * The ver segments leave their 32 tap registers (pair = two rows, tap = column) in place; a hor
+ * segment wants pair = two columns, tap = row.  One v_perm_b32 per hor register picks the two halves
+ * it needs from two ver registers, so the block is never re-packed to bytes between the vertical and
+ * the horizontal edges: 32 unpack + 24 pick + 20 final-pack perms instead of 64 + 44.
+ *
+ * Row r of the block lives in: rows 0,3 = lo,hi of va1 ; rows 1,2 = lo,hi of vb1 ;
+ *                              rows 4,7 = lo,hi of va2 ; rows 5,6 = lo,hi of vb2.
+ * Column c of the block is ver tap: cols 0..3 = p3,p2,p1,p0 ; cols 4..7 = q0,q1,q2,q3.
+ */
+DBK_HD pk pick_lo(pk x, pk y) { return bits_pk(perm(pk_bits(y), pk_bits(x), 0x05040100u)); } /* (x.lo, y.lo) */
+DBK_HD pk pick_hi(pk x, pk y) { return bits_pk(perm(pk_bits(y), pk_bits(x), 0x07060302u)); } /* (x.hi, y.hi) */
+DBK_HD uint32_t row_of(pk a, pk b) { return perm(pk_bits(b), pk_bits(a), 0x02060400u); }     /* [a.lo, b.lo, b.hi, a.hi] */
+
+DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, int tc, int beta)
+{
+    Taps va1 = unpack_ver(L[0], L[3], R[0], R[3]), vb1 = unpack_ver(L[1], L[2], R[1], R[2]);
+    Taps va2 = unpack_ver(L[4], L[7], R[4], R[7]), vb2 = unpack_ver(L[5], L[6], R[5], R[6]);
+    if (bs.ver1 > 0) luma_pairs(va1, vb1, beta, tc); /* cpu.h:164 */
+    if (bs.ver2 > 0) luma_pairs(va2, vb2, beta, tc); /* cpu.h:228 */
+
+    /* hor1: lines = cols 0..3, pair A = cols (0,3) = ver taps (p3,p0), pair B = cols (1,2) = (p2,p1);
+     * P_k = row 3-k, Q_k = row 4+k (cpu.h:287-365) */
+    Taps ha, hb;
+    ha.p0 = pick_hi(va1.p3, va1.p0); hb.p0 = pick_hi(va1.p2, va1.p1); /* row 3 */
+    ha.p1 = pick_hi(vb1.p3, vb1.p0); hb.p1 = pick_hi(vb1.p2, vb1.p1); /* row 2 */
+    ha.p2 = pick_lo(vb1.p3, vb1.p0); hb.p2 = pick_lo(vb1.p2, vb1.p1); /* row 1 */
+    ha.p3 = pick_lo(va1.p3, va1.p0); hb.p3 = pick_lo(va1.p2, va1.p1); /* row 0 */
+    ha.q0 = pick_lo(va2.p3, va2.p0); hb.q0 = pick_lo(va2.p2, va2.p1); /* row 4 */
+    ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1); /* row 5 */
+    ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1); /* row 6 */
+    ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1); /* row 7 */
+    if (bs.hor1 > 0) luma_pairs(ha, hb, beta, tc); /* cpu.h:292 */
+
+    /* hor2: P lines = cols 4..7 (ver taps q0..q3) of rows 3..0, pair A = cols (4,7), B = cols (5,6);
+     * Q = the same registers hor1 just used for its Q side: cols 0..3 of rows 4..7 (cpu.h:368-446) */
+    Taps ga, gb;
+    ga.p0 = pick_hi(va1.q0, va1.q3); gb.p0 = pick_hi(va1.q1, va1.q2); /* row 3 */
+    ga.p1 = pick_hi(vb1.q0, vb1.q3); gb.p1 = pick_hi(vb1.q1, vb1.q2); /* row 2 */
+    ga.p2 = pick_lo(vb1.q0, vb1.q3); gb.p2 = pick_lo(vb1.q1, vb1.q2); /* row 1 */
+    ga.p3 = pick_lo(va1.q0, va1.q3); gb.p3 = pick_lo(va1.q1, va1.q2); /* row 0 */
+    ga.q0 = ha.q0; ga.q1 = ha.q1; ga.q2 = ha.q2; ga.q3 = ha.q3;
+    gb.q0 = hb.q0; gb.q1 = hb.q1; gb.q2 = hb.q2; gb.q3 = hb.q3;
+    if (bs.hor2 > 0) luma_pairs(ga, gb, beta, tc); /* cpu.h:373 */
+
+    /* final pack, once per row dword */
+    L[0] = row_of(ha.p3, hb.p3); L[1] = row_of(ha.p2, hb.p2); L[2] = row_of(ha.p1, hb.p1); L[3] = row_of(ha.p0, hb.p0);
+    L[4] = row_of(ga.q0, gb.q0); L[5] = row_of(ga.q1, gb.q1); L[6] = row_of(ga.q2, gb.q2); L[7] = row_of(ga.q3, gb.q3);
+    R[0] = row_of(ga.p3, gb.p3); R[1] = row_of(ga.p2, gb.p2); R[2] = row_of(ga.p1, gb.p1); R[3] = row_of(ga.p0, gb.p0);
+    {   /* cols 4..7 of rows 4..7: only ver2 touched them; [q0,q1,q2,q3] per row */
+        const uint32_t u1 = perm(pk_bits(va2.q1), pk_bits(va2.q0), 0x06020400u);
+        const uint32_t u2 = perm(pk_bits(va2.q3), pk_bits(va2.q2), 0x06020400u);
+        R[4] = perm(u2, u1, 0x05040100u);
+        R[7] = perm(u2, u1, 0x07060302u);
+        const uint32_t w1 = perm(pk_bits(vb2.q1), pk_bits(vb2.q0), 0x06020400u);
+        const uint32_t w2 = perm(pk_bits(vb2.q3), pk_bits(vb2.q2), 0x06020400u);
+        R[5] = perm(w2, w1, 0x05040100u);
+        R[6] = perm(w2, w1, 0x07060302u);
+    }
+}
+
 /* ---- the whole block: ver1 -> ver2 -> hor1 -> hor2 --------------------------------------- */
 template <bool CHROMA>
 DBK_HD void packed_filter_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, int tc, int beta)
@@ -310,10 +410,7 @@ DBK_HD void packed_filter_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockB
         if (bs.hor1 == 2) chroma_hor(L, L, tc);
         if (bs.hor2 == 2) chroma_hor(R, L, tc);
     } else {
-        if (bs.ver1 > 0) luma_ver<0>(L, R, beta, tc);
-        if (bs.ver2 > 0) luma_ver<4>(L, R, beta, tc);
-        if (bs.hor1 > 0) luma_hor(L, L, beta, tc);
-        if (bs.hor2 > 0) luma_hor(R, L, beta, tc);
+        packed_filter_luma_block(L, R, bs, tc, beta);
     }
 }
 
