@@ -167,12 +167,12 @@ int launch(hevcdbk_context *ctx, const DbkArgs &a, int sample_bytes, bool chroma
 {
     hipError_t e;
     if (variant == HEVCDBK_KERNEL_PACKED || variant == HEVCDBK_KERNEL_DIAG_COPY) {
-        if (!dbk_packed_supports(a, sample_bytes)) return HEVCDBK_ERR_UNSUPPORTED;
-        e = dbk_launch_packed(a, chroma, variant == HEVCDBK_KERNEL_DIAG_COPY ? 1 : 0, s);
+        if (!dbk_packed_supports(a, sample_bytes, chroma)) return HEVCDBK_ERR_UNSUPPORTED;
+        e = dbk_launch_packed(a, sample_bytes, chroma, variant == HEVCDBK_KERNEL_DIAG_COPY ? 1 : 0, s);
     } else if (variant == HEVCDBK_KERNEL_GENERIC) {
         e = dbk_launch_generic(a, sample_bytes, chroma, s);
     } else if (variant == HEVCDBK_KERNEL_AUTO) {
-        e = dbk_packed_supports(a, sample_bytes) ? dbk_launch_packed(a, chroma, 0, s)
+        e = dbk_packed_supports(a, sample_bytes, chroma) ? dbk_launch_packed(a, sample_bytes, chroma, 0, s)
                                                  : dbk_launch_generic(a, sample_bytes, chroma, s);
     } else {
         return HEVCDBK_ERR_ARG;

@@ -26,7 +26,7 @@ struct DbkArgs {
 
 /* one lane per offset block, 32-bit arithmetic; every operand kind */
 hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, hipStream_t stream);
-/* packed 16-bit arithmetic kernel: 8-bit samples, scalar QP, luma or chroma */
+/* packed int16 arithmetic kernels: scalar QP; 8-bit samples (luma or chroma) and 16-bit containers (luma) */
 /* mode 0 = filter, 1 = diagnostic copy (same memory accesses, no arithmetic) */
-hipError_t dbk_launch_packed(const DbkArgs &a, bool chroma, int mode, hipStream_t stream);
-bool dbk_packed_supports(const DbkArgs &a, int sample_bytes);
+hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, int mode, hipStream_t stream);
+bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma);

@@ -226,6 +226,93 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
     }
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+/*
+ * 16-bit containers (bit depth 8..16), luma, scalar QP: same mapping, one lane = one offset block =
+ * 8 rows x 16 bytes.  Interior waves issue 8 back-to-back buffer_load_dwordx4 (a wave's row span is
+ * 1 KiB contiguous, starting 8 bytes before a 16-byte boundary); edge waves use two dwordx2 halves with
+ * out-of-range offsets for out-of-image halves / rows.  Arithmetic = deblock_packed.h on the samples as
+ * they are (no widening needed), so twice the bytes per pixel at the same instruction count: this is
+ * the variant that runs into the HBM roof (BASELINE config 5).
+ */
+template <int MODE, bool NT, bool EDGE>
+__device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, int bx)
+{
+    const bool active = bx < a.nbx;
+    const bool lv = active && bx > 0;
+    const bool rv = bx < a.nbx - 1;
+    const int y0 = by * 8 - 4;
+    const uint32_t xoff = (uint32_t)(bx * 16 - 8);
+    const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.src) + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        a.dst + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
+
+    uint32_t W[8][4];
+    if constexpr (!EDGE) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
+            W[r][0] = w.x; W[r][1] = w.y; W[r][2] = w.z; W[r][3] = w.w;
+        }
+    } else {
+        const uint32_t lo = lv ? xoff : kOob, ro = rv ? xoff + 8u : kOob;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int y = y0 + r;
+            const bool yv = (unsigned)y < (unsigned)a.plane_h; /* wave-uniform */
+            const int soff = yv ? y * (int)a.pitch : 0;
+            const u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(rs, yv ? lo : kOob, soff, aux_bits<NT>());
+            const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rs, yv ? ro : kOob, soff, aux_bits<NT>());
+            W[r][0] = l.x; W[r][1] = l.y; W[r][2] = rr.x; W[r][3] = rr.y;
+        }
+    }
+
+    if constexpr (MODE == 0) {
+        dbk::BlockBs bs{0, 0, 0, 0};
+        if (!EDGE || active)
+            bs = dbk::load_block_bs(a.vert_bs + (long long)f * a.vert_bs_stride, a.hor_bs + (long long)f * a.hor_bs_stride,
+                                    bx, by, a.vstride, a.hstride, a.limit_bx, a.limit_by, a.n_vert, a.n_hor);
+        dbk::packed_filter_luma_block16(W, bs, a.tc, a.beta, a.max_v);
+    }
+
+    if constexpr (!EDGE) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            u32x4 w;
+            w.x = W[r][0]; w.y = W[r][1]; w.z = W[r][2]; w.w = W[r][3];
+            __builtin_amdgcn_raw_buffer_store_b128(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
+        }
+    } else {
+        const uint32_t lo = lv ? xoff : kOob, ro = rv ? xoff + 8u : kOob;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int y = y0 + r;
+            const bool yv = (unsigned)y < (unsigned)a.plane_h;
+            const int soff = yv ? y * (int)a.pitch : 0;
+            u32x2 l, rr;
+            l.x = W[r][0]; l.y = W[r][1]; rr.x = W[r][2]; rr.y = W[r][3];
+            __builtin_amdgcn_raw_buffer_store_b64(l, rd, yv ? lo : kOob, soff, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(rr, rd, yv ? ro : kOob, soff, aux_bits<NT>());
+        }
+    }
+}
+
+template <int MODE, bool NT>
+__global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
+{
+    const int by = blockIdx.x;
+    const int f = blockIdx.y;
+    const int bx = blockIdx.z * (int)blockDim.x + (int)threadIdx.x;
+    const int wave_bx0 = __builtin_amdgcn_readfirstlane(bx) & ~63;
+    const bool interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && by > 0 && by < a.nby - 1;
+    if (interior) packed16_body<MODE, NT, false>(a, by, f, bx);
+    else packed16_body<MODE, NT, true>(a, by, f, bx);
+}
+
 /*
  * Work mapping: ONE WORKGROUP OWNS ONE BLOCK ROW of one frame (up to 1024 offset blocks per
  * workgroup; wider planes take blockIdx.z chunks).  A wave is 64 consecutive bx, so each of its
@@ -250,22 +337,37 @@ __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
 
 } /* namespace */
 
-bool dbk_packed_supports(const DbkArgs &a, int sample_bytes)
+bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
 {
-    return sample_bytes == 1 && a.qp_map == nullptr && a.max_v == 255;
+    if (a.qp_map != nullptr) return false;                       /* scalar QP only */
+    if (sample_bytes == 1) return a.max_v == 255;                /* 8-bit: luma and chroma */
+    return !chroma && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
+           ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0; /* 16-bit containers: luma */
 }
 
-/* development knob: HEVCDBK_TUNE=nt selects the non-temporal variant (A/B runs in bench.py) */
+/* development knobs: HEVCDBK_TUNE=nt selects the non-temporal variant, HEVCDBK_WG caps the workgroup width */
 static bool tune_nt()
 {
     static const bool v = [] { const char *e = getenv("HEVCDBK_TUNE"); return e && strstr(e, "nt") != nullptr; }();
     return v;
 }
+static int tune_wg_cap()
+{
+    static const int v = [] {
+        const char *e = getenv("HEVCDBK_WG");
+        int c = e ? atoi(e) / 64 * 64 : 512;
+        return c < 64 ? 64 : (c > 1024 ? 1024 : c);
+    }();
+    return v;
+}
 
 template <bool NT>
-static void launch_packed_t(const DbkArgs &a, bool chroma, int mode, dim3 grid, dim3 block, hipStream_t stream)
+static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int mode, dim3 grid, dim3 block, hipStream_t stream)
 {
-    if (mode == 1)
+    if (sample_bytes == 2) {
+        if (mode == 1) hipLaunchKernelGGL((dbk_packed16_kernel<1, NT>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT>), grid, block, 0, stream, a);
+    } else if (mode == 1)
         hipLaunchKernelGGL((dbk_packed_kernel<false, 1, NT>), grid, block, 0, stream, a);
     else if (chroma)
         hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT>), grid, block, 0, stream, a);
@@ -273,15 +375,16 @@ static void launch_packed_t(const DbkArgs &a, bool chroma, int mode, dim3 grid, 
         hipLaunchKernelGGL((dbk_packed_kernel<false, 0, NT>), grid, block, 0, stream, a);
 }
 
-hipError_t dbk_launch_packed(const DbkArgs &a, bool chroma, int mode, hipStream_t stream)
+hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, int mode, hipStream_t stream)
 {
     if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
-    int cap = 1024;
-    if (const char *e = getenv("HEVCDBK_WG")) cap = atoi(e) >= 64 ? (atoi(e) / 64 * 64 > 1024 ? 1024 : atoi(e) / 64 * 64) : 1024;
+    /* one workgroup per block row when the row fits (481 blocks at 4K -> 512 threads); wider rows are
+     * split into 512-lane chunks so several workgroups stay resident per CU */
+    const int cap = tune_wg_cap();
     const int per_wg = a.nbx < cap ? a.nbx : cap;
-    dim3 block((per_wg + 63) / 64 * 64, 1, 1);            /* whole waves; one block row per workgroup */
+    dim3 block((per_wg + 63) / 64 * 64, 1, 1);
     dim3 grid(a.nby, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
-    if (tune_nt()) launch_packed_t<true>(a, chroma, mode, grid, block, stream);
-    else launch_packed_t<false>(a, chroma, mode, grid, block, stream);
+    if (tune_nt()) launch_packed_t<true>(a, sample_bytes, chroma, mode, grid, block, stream);
+    else launch_packed_t<false>(a, sample_bytes, chroma, mode, grid, block, stream);
     return hipGetLastError();
 }

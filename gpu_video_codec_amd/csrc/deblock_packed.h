@@ -207,10 +207,10 @@ DBK_HD void strong_pair(Taps &t, pk c)
 }
 
 /* normal filter (cpu.h:1251-1354); m5 / m6 = all-ones halves where cond5 / cond6 hold */
-DBK_HD void normal_pair(Taps &t, int tc, pk m5, pk m6)
+DBK_HD void normal_pair(Taps &t, int tc, pk m5, pk m6, int max_v)
 {
     const pk c = splat(2 * tc), c2 = splat(tc >> 1), lim = splat(10 * tc);
-    const pk zero = splat(0), maxv = splat(255);
+    const pk zero = splat(0), maxv = splat(max_v);
     /* (9(q0-p0) - 3(q1-p1) + 8) >> 4 as two multiply-adds (v_pk_mad_i16) */
     const pk delta = mad_k<9>(t.q0 - t.p0, mad_kc<-3, 8>(t.q1 - t.p1)) >> 4;
     const pk on = (pk_abs(delta) - lim) >> 15;       /* all ones where |delta| < 10*tc (cpu.h:1254) */
@@ -229,7 +229,7 @@ DBK_HD void normal_pair(Taps &t, int tc, pk m5, pk m6)
 }
 
 /* one luma segment given its two unpacked pairs; returns false when nothing changed */
-DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc)
+DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc, int max_v = 255)
 {
     const Decision d = decide(a, beta, tc);
     if (!d.filter) return false;
@@ -239,8 +239,8 @@ DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc)
         strong_pair(b, c);
     } else {
         const pk m5 = splat(d.cond5 ? -1 : 0), m6 = splat(d.cond6 ? -1 : 0);
-        normal_pair(a, tc, m5, m6);
-        normal_pair(b, tc, m5, m6);
+        normal_pair(a, tc, m5, m6, max_v);
+        normal_pair(b, tc, m5, m6, max_v);
     }
     return true;
 }
@@ -298,9 +298,9 @@ DBK_HD void luma_hor(uint32_t (&PX)[8], uint32_t (&L)[8], int beta, int tc)
 
 /* ---- chroma (cpu.h:1431-1488): p0/q0 only, no decisions ------------------------------------------- */
 
-DBK_HD void chroma_pair(pk &p0, pk p1, pk &q0, pk q1, pk tc)
+DBK_HD void chroma_pair(pk &p0, pk p1, pk &q0, pk q1, pk tc, int max_v = 255)
 {
-    const pk zero = splat(0), maxv = splat(255);
+    const pk zero = splat(0), maxv = splat(max_v);
     const pk dp = (((p0 - q0) << 2) + p1 - q1 + splat(4)) >> 3; /* cpu.h:1453 */
     const pk dq = (((q0 - p0) << 2) + q1 - p1 + splat(4)) >> 3; /* cpu.h:1458 */
     const pk np0 = pk_clamp(p0 + pk_clamp(dp, zero - tc, tc), zero, maxv);
@@ -353,16 +353,17 @@ DBK_HD pk pick_lo(pk x, pk y) { return bits_pk(perm(pk_bits(y), pk_bits(x), 0x05
 DBK_HD pk pick_hi(pk x, pk y) { return bits_pk(perm(pk_bits(y), pk_bits(x), 0x07060302u)); } /* (x.hi, y.hi) */
 DBK_HD uint32_t row_of(pk a, pk b) { return perm(pk_bits(b), pk_bits(a), 0x02060400u); }     /* [a.lo, b.lo, b.hi, a.hi] */
 
-DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, int tc, int beta)
+/* the four segments on already-unpacked ver registers; leaves the final values in
+ * ha/hb (cols 0..3 of rows 0..3 as P, taps p3..p0), ga/gb (P = cols 4..7 of rows 0..3, Q = cols 0..3 of
+ * rows 4..7) and va2/vb2 q taps (cols 4..7 of rows 4..7) */
+DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const BlockBs &bs, int tc, int beta,
+                            int max_v, Taps &ha, Taps &hb, Taps &ga, Taps &gb)
 {
-    Taps va1 = unpack_ver(L[0], L[3], R[0], R[3]), vb1 = unpack_ver(L[1], L[2], R[1], R[2]);
-    Taps va2 = unpack_ver(L[4], L[7], R[4], R[7]), vb2 = unpack_ver(L[5], L[6], R[5], R[6]);
-    if (bs.ver1 > 0) luma_pairs(va1, vb1, beta, tc); /* cpu.h:164 */
-    if (bs.ver2 > 0) luma_pairs(va2, vb2, beta, tc); /* cpu.h:228 */
+    if (bs.ver1 > 0) luma_pairs(va1, vb1, beta, tc, max_v); /* cpu.h:164 */
+    if (bs.ver2 > 0) luma_pairs(va2, vb2, beta, tc, max_v); /* cpu.h:228 */
 
     /* hor1: lines = cols 0..3, pair A = cols (0,3) = ver taps (p3,p0), pair B = cols (1,2) = (p2,p1);
      * P_k = row 3-k, Q_k = row 4+k (cpu.h:287-365) */
-    Taps ha, hb;
     ha.p0 = pick_hi(va1.p3, va1.p0); hb.p0 = pick_hi(va1.p2, va1.p1); /* row 3 */
     ha.p1 = pick_hi(vb1.p3, vb1.p0); hb.p1 = pick_hi(vb1.p2, vb1.p1); /* row 2 */
     ha.p2 = pick_lo(vb1.p3, vb1.p0); hb.p2 = pick_lo(vb1.p2, vb1.p1); /* row 1 */
@@ -371,18 +372,26 @@ DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const B
     ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1); /* row 5 */
     ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1); /* row 6 */
     ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1); /* row 7 */
-    if (bs.hor1 > 0) luma_pairs(ha, hb, beta, tc); /* cpu.h:292 */
+    if (bs.hor1 > 0) luma_pairs(ha, hb, beta, tc, max_v); /* cpu.h:292 */
 
     /* hor2: P lines = cols 4..7 (ver taps q0..q3) of rows 3..0, pair A = cols (4,7), B = cols (5,6);
      * Q = the same registers hor1 just used for its Q side: cols 0..3 of rows 4..7 (cpu.h:368-446) */
-    Taps ga, gb;
     ga.p0 = pick_hi(va1.q0, va1.q3); gb.p0 = pick_hi(va1.q1, va1.q2); /* row 3 */
     ga.p1 = pick_hi(vb1.q0, vb1.q3); gb.p1 = pick_hi(vb1.q1, vb1.q2); /* row 2 */
     ga.p2 = pick_lo(vb1.q0, vb1.q3); gb.p2 = pick_lo(vb1.q1, vb1.q2); /* row 1 */
     ga.p3 = pick_lo(va1.q0, va1.q3); gb.p3 = pick_lo(va1.q1, va1.q2); /* row 0 */
     ga.q0 = ha.q0; ga.q1 = ha.q1; ga.q2 = ha.q2; ga.q3 = ha.q3;
     gb.q0 = hb.q0; gb.q1 = hb.q1; gb.q2 = hb.q2; gb.q3 = hb.q3;
-    if (bs.hor2 > 0) luma_pairs(ga, gb, beta, tc); /* cpu.h:373 */
+    if (bs.hor2 > 0) luma_pairs(ga, gb, beta, tc, max_v); /* cpu.h:373 */
+}
+
+/* 8-bit samples: L[r] = cols 0..3, R[r] = cols 4..7 of row r as bytes */
+DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, int tc, int beta)
+{
+    Taps va1 = unpack_ver(L[0], L[3], R[0], R[3]), vb1 = unpack_ver(L[1], L[2], R[1], R[2]);
+    Taps va2 = unpack_ver(L[4], L[7], R[4], R[7]), vb2 = unpack_ver(L[5], L[6], R[5], R[6]);
+    Taps ha, hb, ga, gb;
+    luma_block_core(va1, vb1, va2, vb2, bs, tc, beta, 255, ha, hb, ga, gb);
 
     /* final pack, once per row dword */
     L[0] = row_of(ha.p3, hb.p3); L[1] = row_of(ha.p2, hb.p2); L[2] = row_of(ha.p1, hb.p1); L[3] = row_of(ha.p0, hb.p0);
@@ -398,6 +407,41 @@ DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const B
         R[5] = perm(w2, w1, 0x05040100u);
         R[6] = perm(w2, w1, 0x07060302u);
     }
+}
+
+/* 16-bit containers (bit depth 8..16): W[r][j] = columns (2j, 2j+1) of row r as two uint16.
+ * Same arithmetic; only the moves in and out of the pair registers differ (samples are already
+ * 16 bit wide, so a move is "pick two halves" instead of "pick two bytes and zero-extend"). */
+DBK_HD Taps unpack_ver16(const uint32_t (&a)[4], const uint32_t (&b)[4])
+{
+    Taps t;
+    t.p3 = pick_lo(bits_pk(a[0]), bits_pk(b[0])); t.p2 = pick_hi(bits_pk(a[0]), bits_pk(b[0])); /* cols 0,1 */
+    t.p1 = pick_lo(bits_pk(a[1]), bits_pk(b[1])); t.p0 = pick_hi(bits_pk(a[1]), bits_pk(b[1])); /* cols 2,3 */
+    t.q0 = pick_lo(bits_pk(a[2]), bits_pk(b[2])); t.q1 = pick_hi(bits_pk(a[2]), bits_pk(b[2])); /* cols 4,5 */
+    t.q2 = pick_lo(bits_pk(a[3]), bits_pk(b[3])); t.q3 = pick_hi(bits_pk(a[3]), bits_pk(b[3])); /* cols 6,7 */
+    return t;
+}
+
+DBK_HD void packed_filter_luma_block16(uint32_t (&W)[8][4], const BlockBs &bs, int tc, int beta, int max_v)
+{
+    Taps va1 = unpack_ver16(W[0], W[3]), vb1 = unpack_ver16(W[1], W[2]);
+    Taps va2 = unpack_ver16(W[4], W[7]), vb2 = unpack_ver16(W[5], W[6]);
+    Taps ha, hb, ga, gb;
+    luma_block_core(va1, vb1, va2, vb2, bs, tc, beta, max_v, ha, hb, ga, gb);
+
+    /* pair A = cols (0,3) / (4,7), pair B = cols (1,2) / (5,6):  (c0,c1) = (A.lo,B.lo), (c2,c3) = (B.hi,A.hi) */
+#define DBK_ROW16(r, A, B, j)                                 \
+    W[r][j] = pk_bits(pick_lo(A, B));                          \
+    W[r][j + 1] = pk_bits(pick_hi(B, A));
+    DBK_ROW16(0, ha.p3, hb.p3, 0) DBK_ROW16(1, ha.p2, hb.p2, 0) DBK_ROW16(2, ha.p1, hb.p1, 0) DBK_ROW16(3, ha.p0, hb.p0, 0)
+    DBK_ROW16(4, ga.q0, gb.q0, 0) DBK_ROW16(5, ga.q1, gb.q1, 0) DBK_ROW16(6, ga.q2, gb.q2, 0) DBK_ROW16(7, ga.q3, gb.q3, 0)
+    DBK_ROW16(0, ga.p3, gb.p3, 2) DBK_ROW16(1, ga.p2, gb.p2, 2) DBK_ROW16(2, ga.p1, gb.p1, 2) DBK_ROW16(3, ga.p0, gb.p0, 2)
+#undef DBK_ROW16
+    /* cols 4..7 of rows 4..7 from the ver2 registers: rows (4,7) = lo,hi of va2 ; rows (5,6) of vb2 */
+    W[4][2] = pk_bits(pick_lo(va2.q0, va2.q1)); W[4][3] = pk_bits(pick_lo(va2.q2, va2.q3));
+    W[7][2] = pk_bits(pick_hi(va2.q0, va2.q1)); W[7][3] = pk_bits(pick_hi(va2.q2, va2.q3));
+    W[5][2] = pk_bits(pick_lo(vb2.q0, vb2.q1)); W[5][3] = pk_bits(pick_lo(vb2.q2, vb2.q3));
+    W[6][2] = pk_bits(pick_hi(vb2.q0, vb2.q1)); W[6][3] = pk_bits(pick_hi(vb2.q2, vb2.q3));
 }
 
 /* ---- the whole block: ver1 -> ver2 -> hor1 -> hor2 --------------------------------------- */

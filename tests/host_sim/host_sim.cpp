@@ -62,7 +62,21 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
                 for (int s = 0; s < 4; s++) { q.tc[s] = tc; q.beta[s] = beta; }
             }
 #if HAVE_PACKED
-            if (packed) {
+            if (packed && sizeof(T) == 2 && !is_chroma && !map) {
+                /* 16-bit containers through the packed core (luma, scalar QP) */
+                uint32_t W[8][4];
+                for (int r = 0; r < 8; r++)
+                    for (int j = 0; j < 4; j++) W[r][j] = (uint32_t)v[r][2 * j] | ((uint32_t)v[r][2 * j + 1] << 16);
+                dbk::packed_filter_luma_block16(W, bs, tc, beta, max_v);
+                for (int r = 0; r < 8; r++)
+                    for (int j = 0; j < 4; j++) {
+                        v[r][2 * j] = W[r][j] & 0xffff;
+                        v[r][2 * j + 1] = W[r][j] >> 16;
+                    }
+                store_block(plane, pitch_s, w, h, bx, by, v);
+                continue;
+            }
+            if (packed && sizeof(T) == 1) {
                 uint32_t L[8], R[8];
                 for (int r = 0; r < 8; r++) {
                     L[r] = (uint32_t)v[r][0] | ((uint32_t)v[r][1] << 8) | ((uint32_t)v[r][2] << 16) | ((uint32_t)v[r][3] << 24);

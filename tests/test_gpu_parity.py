@@ -148,9 +148,19 @@ def test_device_10bit_luma_and_chroma(ctx, oracle):
     """BASELINE config 5 arithmetic (16-bit containers).  Parity vs the oracle's uint16 instantiation,
     itself pinned at 8 bit only ("parity unpinned" beyond that: the reference is 8-bit)."""
     from gpu_video_codec_amd import synth, _lib
-    y = synth.blocky_plane(1928, 264, seed=4, bit_depth=10)
-    got = run_batch(ctx, y[None], 32, variant=_lib.KERNEL_AUTO, bit_depth=10)
-    assert np.array_equal(got[0], oracle.filter_plane(y, 32, bit_depth=10))
+    y = synth.blocky_plane(1928, 264, seed=4, bit_depth=10).copy()
+    y[:64, :256] = np.random.default_rng(2).integers(0, 1024, (64, 256), dtype=np.uint16)
+    y[200:, 1500:] = 1023
+    vb, hb = oracle.lcg_bs(1928, 264, 77)
+    for variant in (_lib.KERNEL_GENERIC, _lib.KERNEL_PACKED, _lib.KERNEL_AUTO):  # packed = dbk_packed16_kernel
+        for qp in (22, 32, 51):
+            got = run_batch(ctx, np.stack([y, y[::-1]]), qp, variant=variant, bit_depth=10, bs=[(vb, hb), oracle.default_bs(1928, 264)])
+            assert np.array_equal(got[0], oracle.filter_plane(y, qp, bit_depth=10, vert_bs=vb, hor_bs=hb)), (variant, qp)
+            assert np.array_equal(got[1], oracle.filter_plane(y[::-1], qp, bit_depth=10)), (variant, qp)
+    for size in [(8, 8), (16, 24), (504, 16), (1032, 40)]:  # tiny / ragged rows through the 16-bit packed kernel
+        t = synth.blocky_plane(size[0], size[1], seed=9, bit_depth=12)
+        got = run_batch(ctx, t[None], 40, variant=_lib.KERNEL_PACKED, bit_depth=12)
+        assert np.array_equal(got[0], oracle.filter_plane(t, 40, bit_depth=12)), size
     got = run_batch(ctx, y[None], 40, variant=_lib.KERNEL_AUTO, bit_depth=10, is_chroma=True)
     assert np.array_equal(got[0], oracle.filter_plane(y, 40, bit_depth=10, is_chroma=True))
     # 8-bit data in 16-bit containers == the reference-pinned 8-bit result

@@ -101,3 +101,24 @@ def test_16bit_and_qp_map_generic(sim, oracle):
     c = synth.blocky_plane(384, 288, seed=3)
     assert np.array_equal(run_sim(sim, oracle, c, 0, qp_map=qmap, is_chroma=True),
                           oracle.filter_plane(c, 0, qp_map=qmap, is_chroma=True))
+
+
+def test_packed_16bit_luma(sim, oracle, golden_inputs):
+    """The packed core on 16-bit containers: 10/12-bit synthetic data vs the oracle, and 8-bit data in
+    16-bit containers vs the reference-pinned 8-bit result (the pinned degenerate case)."""
+    if not sim.host_sim_have_packed():
+        pytest.skip("packed core not built")
+    from gpu_video_codec_amd import synth
+    rng = np.random.default_rng(21)
+    for bd in (10, 12):
+        for (w, h) in [(8, 8), (64, 48), (520, 72)]:
+            for qp in (22, 32, 45, 51):
+                y = synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30)), bit_depth=bd).copy()
+                y[: max(h // 4, 1), : max(w // 4, 1)] = rng.integers(0, 1 << bd, (max(h // 4, 1), max(w // 4, 1)), dtype=np.uint16)
+                y[h // 2:, w // 2:] = (1 << bd) - 1
+                vb, hb = oracle.lcg_bs(w, h, int(rng.integers(1, 1000)))
+                got = run_sim(sim, oracle, y, qp, bit_depth=bd, vbs=vb, hbs=hb, packed=1)
+                assert np.array_equal(got, oracle.filter_plane(y, qp, bit_depth=bd, vert_bs=vb, hor_bs=hb)), (bd, w, h, qp)
+    y8, _, _ = oracle.split_yuv420(golden_inputs["image2"], 768, 576)
+    got = run_sim(sim, oracle, y8.astype(np.uint16), 30, bit_depth=8, packed=1)
+    assert np.array_equal(got, oracle.filter_plane(y8, 30).astype(np.uint16))

@@ -26,17 +26,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_pmc(counter, variant, frames, outdir, steps=3):
+def run_pmc(counter, variant, frames, outdir, steps=3, extra=()):
     d = os.path.join(outdir, "%s_%s" % (counter, variant))
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1",
-           "--variant", variant, "--frames", str(frames), "--no-cpu-baseline", "--no-e2e"]
+           "--variant", variant, "--frames", str(frames), "--no-cpu-baseline", "--no-e2e"] + list(extra)
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     vals = []
     for fn in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(fn)):
-            if r["Counter_Name"] == counter and "dbk_packed_kernel" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and "dbk_packed" in r["Kernel_Name"]:
                 vals.append(float(r["Counter_Value"]))
     assert vals, "no %s rows for %s" % (counter, variant)
     vals.sort()
@@ -49,20 +49,23 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--outdir", default=os.path.join(ROOT, "gpurun_out", "traffic"))
     args = ap.parse_args()
     os.makedirs(args.outdir, exist_ok=True)
     w, h, F = args.width, args.height, args.frames
-    known = w * h * F  # bytes read == bytes written by the copy variant
+    sb = 1 if args.bit_depth == 8 else 2
+    extra = ["--width", str(w), "--height", str(h), "--bit-depth", str(args.bit_depth)]
+    known = w * h * F * sb  # bytes read == bytes written by the copy variant
     raw = {}
     for variant in ("copy", "packed"):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            raw["%s_%s" % (counter, variant)] = run_pmc(counter, variant, F, args.outdir) * 1024.0
+            raw["%s_%s" % (counter, variant)] = run_pmc(counter, variant, F, args.outdir, extra=extra) * 1024.0
     read_corr = known / raw["FETCH_SIZE_copy"]
     write_corr = known / raw["WRITE_SIZE_copy"]
     bs_bytes = ((w // 8 + 1) * (h // 8) + (h // 8 + 1) * (w // 8)) * F
     out = {
-        "tag": args.tag, "workload": {"width": w, "height": h, "frames_per_launch": F, "bit_depth": 8},
+        "tag": args.tag, "workload": {"width": w, "height": h, "frames_per_launch": F, "bit_depth": args.bit_depth},
         "raw_bytes_per_launch": raw,
         "calibration": {"known_copy_bytes_each_way": known, "read_corr": read_corr, "write_corr": write_corr,
                         "note": "correction = known bytes / counter on the diagnostic copy variant (8 B/lane, 4-byte aligned)"},
