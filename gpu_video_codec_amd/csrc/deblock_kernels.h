@@ -22,6 +22,7 @@ struct DbkArgs {
     int map_stride, ctu_log2;
     long long map_frame_stride;
     uint8_t tc_tab[52], beta_tab[52];
+    int diag_xshift; /* diagnostic copy mode only: byte shift of every row span (alignment experiments) */
 };
 
 /* one lane per offset block, 32-bit arithmetic; every operand kind */

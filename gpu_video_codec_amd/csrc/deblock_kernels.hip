@@ -168,7 +168,7 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
     const bool lv = active && bx > 0;   /* cols 0..3 inside the image */
     const bool rv = bx < a.nbx - 1;     /* cols 4..7 inside the image (implies active) */
     const int y0 = by * 8 - 4;
-    const uint32_t xoff = (uint32_t)(bx * 8 - 4);
+    const uint32_t xoff = (uint32_t)(bx * 8 - 4) + (MODE == 1 ? (uint32_t)a.diag_xshift : 0u);
     const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -243,7 +243,7 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
     const bool lv = active && bx > 0;
     const bool rv = bx < a.nbx - 1;
     const int y0 = by * 8 - 4;
-    const uint32_t xoff = (uint32_t)(bx * 16 - 8);
+    const uint32_t xoff = (uint32_t)(bx * 16 - 8) + (MODE == 1 ? (uint32_t)a.diag_xshift : 0u);
     const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -341,8 +341,10 @@ bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
 {
     if (a.qp_map != nullptr) return false;                       /* scalar QP only */
     if (sample_bytes == 1) return a.max_v == 255;                /* 8-bit: luma and chroma */
-    return !chroma && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
-           ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0; /* 16-bit containers: luma */
+    /* 16-bit containers: luma, and only while every intermediate fits int16: the normal filter's
+     * 9*(q0-p0) - 3*(q1-p1) + 8 needs 12*max_v + 8 <= 32767, i.e. bit depth <= 11 */
+    return !chroma && a.max_v <= 2047 && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
+           ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0;
 }
 
 /* development knobs: HEVCDBK_TUNE=nt selects the non-temporal variant, HEVCDBK_WG caps the workgroup width */
@@ -384,7 +386,12 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
     const int per_wg = a.nbx < cap ? a.nbx : cap;
     dim3 block((per_wg + 63) / 64 * 64, 1, 1);
     dim3 grid(a.nby, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
-    if (tune_nt()) launch_packed_t<true>(a, sample_bytes, chroma, mode, grid, block, stream);
-    else launch_packed_t<false>(a, sample_bytes, chroma, mode, grid, block, stream);
+    DbkArgs b = a;
+    if (mode == 1) { /* diagnostic copy only: HEVCDBK_TUNE=align shifts the spans onto their natural alignment */
+        const char *e = getenv("HEVCDBK_TUNE");
+        b.diag_xshift = (e && strstr(e, "align")) ? 4 * sample_bytes : 0;
+    }
+    if (tune_nt()) launch_packed_t<true>(b, sample_bytes, chroma, mode, grid, block, stream);
+    else launch_packed_t<false>(b, sample_bytes, chroma, mode, grid, block, stream);
     return hipGetLastError();
 }

@@ -206,11 +206,12 @@ DBK_HD void strong_pair(Taps &t, pk c)
     t.q0 = nq0; t.q1 = nq1; t.q2 = nq2;
 }
 
-/* normal filter (cpu.h:1251-1354); m5 / m6 = all-ones halves where cond5 / cond6 hold */
-DBK_HD void normal_pair(Taps &t, int tc, pk m5, pk m6, int max_v)
+/* normal filter (cpu.h:1251-1354) up to, but not including, the final Clip2 to [0, max_v];
+ * m5 / m6 = all-ones halves where cond5 / cond6 hold */
+DBK_HD void normal_pair_unclipped(Taps &t, int tc, pk m5, pk m6)
 {
     const pk c = splat(2 * tc), c2 = splat(tc >> 1), lim = splat(10 * tc);
-    const pk zero = splat(0), maxv = splat(max_v);
+    const pk zero = splat(0);
     /* (9(q0-p0) - 3(q1-p1) + 8) >> 4 as two multiply-adds (v_pk_mad_i16) */
     const pk delta = mad_k<9>(t.q0 - t.p0, mad_kc<-3, 8>(t.q1 - t.p1)) >> 4;
     const pk on = (pk_abs(delta) - lim) >> 15;       /* all ones where |delta| < 10*tc (cpu.h:1254) */
@@ -222,10 +223,30 @@ DBK_HD void normal_pair(Taps &t, int tc, pk m5, pk m6, int max_v)
     const pk dp1 = pk_clamp(mad_k<2>(D, mad_k<-2>(t.p1, xp)) >> 2, zero - c2, c2);
     const pk dq1 = pk_clamp(mad_k<-2>(D, mad_k<-2>(t.q1, xq)) >> 2, zero - c2, c2);
     const pk Dm = D & on;
-    t.p0 = pk_clamp(t.p0 + Dm, zero, maxv);
-    t.q0 = pk_clamp(t.q0 - Dm, zero, maxv);
-    t.p1 = pk_clamp(t.p1 + (dp1 & on & m5), zero, maxv);
-    t.q1 = pk_clamp(t.q1 + (dq1 & on & m6), zero, maxv);
+    t.p0 = t.p0 + Dm;
+    t.q0 = t.q0 - Dm;
+    t.p1 = t.p1 + (dp1 & on & m5);
+    t.q1 = t.q1 + (dq1 & on & m6);
+}
+
+/* both pairs of a normal-filtered segment.  The final Clip2 (cpu.h:1268-1275) only ever acts on samples
+ * within 2*tc of 0 or max_v; one OR over the eight results shows whether any field left [0, max_v]
+ * (a negative field has its top bits set, a too-large one has a bit above max_v), and the 16
+ * min/max instructions run only in waves where some lane needs them. */
+DBK_HD void normal_pairs(Taps &a, Taps &b, int tc, pk m5, pk m6, int max_v)
+{
+    normal_pair_unclipped(a, tc, m5, m6);
+    normal_pair_unclipped(b, tc, m5, m6);
+    const uint32_t over = (pk_bits(a.p0) | pk_bits(a.q0) | pk_bits(a.p1) | pk_bits(a.q1) |
+                           pk_bits(b.p0) | pk_bits(b.q0) | pk_bits(b.p1) | pk_bits(b.q1)) &
+                          (0x00010001u * (0xffffu & ~(uint32_t)max_v));
+    if (over) {
+        const pk zero = splat(0), maxv = splat(max_v);
+        a.p0 = pk_clamp(a.p0, zero, maxv); a.q0 = pk_clamp(a.q0, zero, maxv);
+        a.p1 = pk_clamp(a.p1, zero, maxv); a.q1 = pk_clamp(a.q1, zero, maxv);
+        b.p0 = pk_clamp(b.p0, zero, maxv); b.q0 = pk_clamp(b.q0, zero, maxv);
+        b.p1 = pk_clamp(b.p1, zero, maxv); b.q1 = pk_clamp(b.q1, zero, maxv);
+    }
 }
 
 /* one luma segment given its two unpacked pairs; returns false when nothing changed */
@@ -239,8 +260,7 @@ DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc, int max_v = 255)
         strong_pair(b, c);
     } else {
         const pk m5 = splat(d.cond5 ? -1 : 0), m6 = splat(d.cond6 ? -1 : 0);
-        normal_pair(a, tc, m5, m6, max_v);
-        normal_pair(b, tc, m5, m6, max_v);
+        normal_pairs(a, b, tc, m5, m6, max_v);
     }
     return true;
 }

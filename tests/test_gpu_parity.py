@@ -158,9 +158,17 @@ def test_device_10bit_luma_and_chroma(ctx, oracle):
             assert np.array_equal(got[0], oracle.filter_plane(y, qp, bit_depth=10, vert_bs=vb, hor_bs=hb)), (variant, qp)
             assert np.array_equal(got[1], oracle.filter_plane(y[::-1], qp, bit_depth=10)), (variant, qp)
     for size in [(8, 8), (16, 24), (504, 16), (1032, 40)]:  # tiny / ragged rows through the 16-bit packed kernel
-        t = synth.blocky_plane(size[0], size[1], seed=9, bit_depth=12)
-        got = run_batch(ctx, t[None], 40, variant=_lib.KERNEL_PACKED, bit_depth=12)
-        assert np.array_equal(got[0], oracle.filter_plane(t, 40, bit_depth=12)), size
+        t = synth.blocky_plane(size[0], size[1], seed=9, bit_depth=11)
+        got = run_batch(ctx, t[None], 40, variant=_lib.KERNEL_PACKED, bit_depth=11)
+        assert np.array_equal(got[0], oracle.filter_plane(t, 40, bit_depth=11)), size
+    # 12 bit and up: intermediates no longer fit int16 -> AUTO falls back to the generic 32-bit kernel, PACKED refuses
+    t = np.random.default_rng(5).integers(0, 4096, (64, 256), dtype=np.uint16)
+    got = run_batch(ctx, t[None], 51, variant=_lib.KERNEL_AUTO, bit_depth=12)
+    assert np.array_equal(got[0], oracle.filter_plane(t, 51, bit_depth=12))
+    from gpu_video_codec_amd import deblock
+    with pytest.raises(deblock.DeblockError) as e:
+        run_batch(ctx, t[None], 51, variant=_lib.KERNEL_PACKED, bit_depth=12)
+    assert e.value.code == _lib.ERR_UNSUPPORTED
     got = run_batch(ctx, y[None], 40, variant=_lib.KERNEL_AUTO, bit_depth=10, is_chroma=True)
     assert np.array_equal(got[0], oracle.filter_plane(y, 40, bit_depth=10, is_chroma=True))
     # 8-bit data in 16-bit containers == the reference-pinned 8-bit result
