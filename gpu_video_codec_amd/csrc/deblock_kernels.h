@@ -22,6 +22,9 @@ struct DbkArgs {
     int map_stride, ctu_log2;
     long long map_frame_stride;
     uint8_t tc_tab[52], beta_tab[52];
+    /* row-major block numbering of the packed kernels (filled by dbk_launch_packed) */
+    int nb_total, wpf;              /* blocks per frame, workgroups per frame */
+    uint32_t magic_wpf, magic_nbx;  /* floor(2^32/d)+1 reciprocals */
     int diag_xshift; /* diagnostic copy mode only: byte shift of every row span (alignment experiments) */
 };
 

@@ -162,11 +162,11 @@ constexpr uint32_t kOob = 0xfffffff0u; /* voffset >= num_records: load returns 0
  * MODE 0 = filter, MODE 1 = diagnostic copy (same loads/stores, no arithmetic).
  */
 template <bool CHROMA, int MODE, bool NT, bool EDGE>
-__device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int bx)
+__device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int bx, bool active)
 {
-    const bool active = bx < a.nbx;
-    const bool lv = active && bx > 0;   /* cols 0..3 inside the image */
-    const bool rv = bx < a.nbx - 1;     /* cols 4..7 inside the image (implies active) */
+    /* EDGE == false: by is wave-uniform (scalar row offsets); EDGE == true: by and bx may differ per lane */
+    const bool lv = active && bx > 0;            /* cols 0..3 inside the image */
+    const bool rv = active && bx < a.nbx - 1;    /* cols 4..7 inside the image */
     const int y0 = by * 8 - 4;
     const uint32_t xoff = (uint32_t)(bx * 8 - 4) + (MODE == 1 ? (uint32_t)a.diag_xshift : 0u);
     const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
@@ -185,15 +185,14 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             R[r] = w.y;
         }
     } else {
-        /* straight-line: an out-of-image half or row gets an out-of-range offset (load -> 0) */
-        const uint32_t lo = lv ? xoff : kOob, ro = rv ? xoff + 4u : kOob;
+        /* straight-line, per-lane offsets: an out-of-image half or row gets an out-of-range offset (load -> 0) */
+        const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const int y = y0 + r;
-            const bool yv = (unsigned)y < (unsigned)a.plane_h; /* wave-uniform */
-            const int soff = yv ? y * (int)a.pitch : 0;
-            L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, yv ? lo : kOob, soff, aux_bits<NT>());
-            R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, yv ? ro : kOob, soff, aux_bits<NT>());
+            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
+            const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
+            L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
+            R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && rv) ? off + 4u : kOob, 0, aux_bits<NT>());
         }
     }
 
@@ -214,14 +213,13 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             __builtin_amdgcn_raw_buffer_store_b64(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
         }
     } else {
-        const uint32_t lo = lv ? xoff : kOob, ro = rv ? xoff + 4u : kOob;
+        const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const int y = y0 + r;
-            const bool yv = (unsigned)y < (unsigned)a.plane_h;
-            const int soff = yv ? y * (int)a.pitch : 0;
-            __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, yv ? lo : kOob, soff, aux_bits<NT>());
-            __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, yv ? ro : kOob, soff, aux_bits<NT>());
+            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
+            const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
+            __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, (yv && rv) ? off + 4u : kOob, 0, aux_bits<NT>());
         }
     }
 }
@@ -237,11 +235,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
  * the variant that runs into the HBM roof (BASELINE config 5).
  */
 template <int MODE, bool NT, bool EDGE>
-__device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, int bx)
+__device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, int bx, bool active)
 {
-    const bool active = bx < a.nbx;
     const bool lv = active && bx > 0;
-    const bool rv = bx < a.nbx - 1;
+    const bool rv = active && bx < a.nbx - 1;
     const int y0 = by * 8 - 4;
     const uint32_t xoff = (uint32_t)(bx * 16 - 8) + (MODE == 1 ? (uint32_t)a.diag_xshift : 0u);
     const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
@@ -259,14 +256,13 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
             W[r][0] = w.x; W[r][1] = w.y; W[r][2] = w.z; W[r][3] = w.w;
         }
     } else {
-        const uint32_t lo = lv ? xoff : kOob, ro = rv ? xoff + 8u : kOob;
+        const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const int y = y0 + r;
-            const bool yv = (unsigned)y < (unsigned)a.plane_h; /* wave-uniform */
-            const int soff = yv ? y * (int)a.pitch : 0;
-            const u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(rs, yv ? lo : kOob, soff, aux_bits<NT>());
-            const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rs, yv ? ro : kOob, soff, aux_bits<NT>());
+            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
+            const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
+            const u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(rs, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
+            const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rs, (yv && rv) ? off + 8u : kOob, 0, aux_bits<NT>());
             W[r][0] = l.x; W[r][1] = l.y; W[r][2] = rr.x; W[r][3] = rr.y;
         }
     }
@@ -287,30 +283,83 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
             __builtin_amdgcn_raw_buffer_store_b128(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
         }
     } else {
-        const uint32_t lo = lv ? xoff : kOob, ro = rv ? xoff + 8u : kOob;
+        const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const int y = y0 + r;
-            const bool yv = (unsigned)y < (unsigned)a.plane_h;
-            const int soff = yv ? y * (int)a.pitch : 0;
+            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
+            const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
             u32x2 l, rr;
             l.x = W[r][0]; l.y = W[r][1]; rr.x = W[r][2]; rr.y = W[r][3];
-            __builtin_amdgcn_raw_buffer_store_b64(l, rd, yv ? lo : kOob, soff, aux_bits<NT>());
-            __builtin_amdgcn_raw_buffer_store_b64(rr, rd, yv ? ro : kOob, soff, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(l, rd, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(rr, rd, (yv && rv) ? off + 8u : kOob, 0, aux_bits<NT>());
         }
     }
 }
 
-template <int MODE, bool NT>
+/*
+ * Work mapping of the packed kernels (see WaveCoords below).
+ */
+struct WaveCoords {
+    int f;          /* frame (scalar) */
+    int by, bx;     /* offset block of this lane */
+    bool active;    /* lane owns a block */
+    bool interior;  /* wave-uniform: all 64 lanes in one block row, none touches the frame border */
+};
+
+/*
+ * LINEAR == false: one workgroup per block row (blockIdx.x = by, .y = frame, .z = 512-lane chunk).
+ * LINEAR == true : the offset blocks of a frame are numbered row-major, t = by*nbx + bx, and dealt to
+ *   lanes in that order, so no lane idles at a row end (481 blocks per row at 4K leave 31 of 512 lanes
+ *   idle otherwise) and only the ~1-in-7 waves that contain a row end / frame border take the per-lane
+ *   path.  Workgroups are renumbered so that the 8 XCDs (round-robin over blockIdx, an observation used
+ *   for speed only) each get a CONTIGUOUS range of workgroups: neighbouring workgroups share the cache
+ *   lines at their common boundary, and their partial writes then merge in one XCD's L2.
+ *   Divisions are exact multiply-high by host-computed reciprocals (dividend < 2^32 / divisor).
+ */
+template <bool LINEAR>
+__device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    if constexpr (!LINEAR) {
+        c.by = blockIdx.x;
+        c.f = blockIdx.y;
+        c.bx = blockIdx.z * (int)blockDim.x + (int)threadIdx.x;
+        const int wave_bx0 = __builtin_amdgcn_readfirstlane(c.bx) & ~63;
+        c.active = c.bx < a.nbx;
+        c.interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && c.by > 0 && c.by < a.nby - 1;
+        return true;
+    } else {
+        const uint32_t id = blockIdx.x, per_xcd = gridDim.x >> 3;
+        const uint32_t logical = (id & 7u) * per_xcd + (id >> 3);
+        const uint32_t f = __umulhi(logical, a.magic_wpf);
+        if (f >= (uint32_t)a.n_frames) return false; /* padding workgroup */
+        c.f = (int)f;
+        const uint32_t wg = logical - f * (uint32_t)a.wpf;
+        const uint32_t t0 = wg * blockDim.x + (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u); /* scalar */
+        const uint32_t by0 = __umulhi(t0, a.magic_nbx), bx0 = t0 - by0 * (uint32_t)a.nbx;
+        c.interior = bx0 >= 1u && bx0 + 63u <= (uint32_t)a.nbx - 2u && by0 >= 1u && by0 + 2u <= (uint32_t)a.nby;
+        if (c.interior) {
+            c.by = (int)by0;
+            c.bx = (int)bx0 + lane;
+            c.active = true;
+        } else {
+            const uint32_t t = t0 + (uint32_t)lane;
+            const uint32_t by = __umulhi(t, a.magic_nbx);
+            c.by = (int)by;
+            c.bx = (int)(t - by * (uint32_t)a.nbx);
+            c.active = t < (uint32_t)a.nb_total;
+        }
+        return true;
+    }
+}
+
+template <int MODE, bool NT, bool LINEAR>
 __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
 {
-    const int by = blockIdx.x;
-    const int f = blockIdx.y;
-    const int bx = blockIdx.z * (int)blockDim.x + (int)threadIdx.x;
-    const int wave_bx0 = __builtin_amdgcn_readfirstlane(bx) & ~63;
-    const bool interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && by > 0 && by < a.nby - 1;
-    if (interior) packed16_body<MODE, NT, false>(a, by, f, bx);
-    else packed16_body<MODE, NT, true>(a, by, f, bx);
+    WaveCoords c;
+    if (!wave_coords<LINEAR>(a, c)) return;
+    if (c.interior) packed16_body<MODE, NT, false>(a, c.by, c.f, c.bx, true);
+    else packed16_body<MODE, NT, true>(a, c.by, c.f, c.bx, c.active);
 }
 
 /*
@@ -322,17 +371,13 @@ __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
  * both halves of every such line on one CU / one XCD L2, where the partial writes merge before
  * write-back.
  */
-template <bool CHROMA, int MODE, bool NT>
+template <bool CHROMA, int MODE, bool NT, bool LINEAR>
 __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
 {
-    const int by = blockIdx.x; /* scalar */
-    const int f = blockIdx.y;  /* scalar */
-    const int bx = blockIdx.z * (int)blockDim.x + (int)threadIdx.x;
-    const int wave_bx0 = __builtin_amdgcn_readfirstlane(bx) & ~63;
-    /* wave-uniform: every lane owns both halves of all 8 rows */
-    const bool interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && by > 0 && by < a.nby - 1;
-    if (interior) packed_body<CHROMA, MODE, NT, false>(a, by, f, bx);
-    else packed_body<CHROMA, MODE, NT, true>(a, by, f, bx);
+    WaveCoords c;
+    if (!wave_coords<LINEAR>(a, c)) return;
+    if (c.interior) packed_body<CHROMA, MODE, NT, false>(a, c.by, c.f, c.bx, true);
+    else packed_body<CHROMA, MODE, NT, true>(a, c.by, c.f, c.bx, c.active);
 }
 
 } /* namespace */
@@ -363,35 +408,58 @@ static int tune_wg_cap()
     return v;
 }
 
-template <bool NT>
+static bool tune_rowmap()
+{
+    static const bool v = [] { const char *e = getenv("HEVCDBK_TUNE"); return e && strstr(e, "rowmap") != nullptr; }();
+    return v;
+}
+
+template <bool NT, bool LINEAR>
 static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int mode, dim3 grid, dim3 block, hipStream_t stream)
 {
     if (sample_bytes == 2) {
-        if (mode == 1) hipLaunchKernelGGL((dbk_packed16_kernel<1, NT>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT>), grid, block, 0, stream, a);
+        if (mode == 1) hipLaunchKernelGGL((dbk_packed16_kernel<1, NT, LINEAR>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR>), grid, block, 0, stream, a);
     } else if (mode == 1)
-        hipLaunchKernelGGL((dbk_packed_kernel<false, 1, NT>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((dbk_packed_kernel<false, 1, NT, LINEAR>), grid, block, 0, stream, a);
     else if (chroma)
-        hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT, LINEAR>), grid, block, 0, stream, a);
     else
-        hipLaunchKernelGGL((dbk_packed_kernel<false, 0, NT>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((dbk_packed_kernel<false, 0, NT, LINEAR>), grid, block, 0, stream, a);
 }
 
 hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, int mode, hipStream_t stream)
 {
     if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
-    /* one workgroup per block row when the row fits (481 blocks at 4K -> 512 threads); wider rows are
-     * split into 512-lane chunks so several workgroups stay resident per CU */
-    const int cap = tune_wg_cap();
-    const int per_wg = a.nbx < cap ? a.nbx : cap;
-    dim3 block((per_wg + 63) / 64 * 64, 1, 1);
-    dim3 grid(a.nby, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
     DbkArgs b = a;
     if (mode == 1) { /* diagnostic copy only: HEVCDBK_TUNE=align shifts the spans onto their natural alignment */
         const char *e = getenv("HEVCDBK_TUNE");
         b.diag_xshift = (e && strstr(e, "align")) ? 4 * sample_bytes : 0;
     }
-    if (tune_nt()) launch_packed_t<true>(b, sample_bytes, chroma, mode, grid, block, stream);
-    else launch_packed_t<false>(b, sample_bytes, chroma, mode, grid, block, stream);
+    const int cap = tune_wg_cap();
+    const long long nb = (long long)a.nbx * a.nby;
+    /* row-major block numbering needs exact 32-bit reciprocal division: dividends < 2^32 / divisor */
+    const int wg = (int)(nb < cap ? (nb + 63) / 64 * 64 : cap);
+    const long long wpf = (nb + wg - 1) / wg;
+    const long long total = (wpf * a.n_frames + 7) / 8 * 8; /* multiple of 8: one contiguous range per XCD */
+    /* reciprocal division floor(2^32/d)+1 is exact for dividends < 2^32/d and needs d >= 2 */
+    const bool linear = !tune_rowmap() && wpf >= 2 && a.nbx >= 2 && (nb + 1024) * a.nbx < (1ll << 32) &&
+                        total * wpf < (1ll << 32) && total < (1ll << 31);
+    if (linear) {
+        b.nb_total = (int)nb;
+        b.wpf = (int)wpf;
+        b.magic_wpf = (uint32_t)((1ull << 32) / (unsigned long long)wpf + 1ull);
+        b.magic_nbx = (uint32_t)((1ull << 32) / (unsigned long long)a.nbx + 1ull);
+        dim3 block(wg, 1, 1), grid((unsigned)total, 1, 1);
+        if (tune_nt()) launch_packed_t<true, true>(b, sample_bytes, chroma, mode, grid, block, stream);
+        else launch_packed_t<false, true>(b, sample_bytes, chroma, mode, grid, block, stream);
+        return hipGetLastError();
+    }
+    /* small planes / degenerate divisors: one workgroup per block row, wider rows split into cap-lane chunks */
+    const int per_wg = a.nbx < cap ? a.nbx : cap;
+    dim3 block((per_wg + 63) / 64 * 64, 1, 1);
+    dim3 grid(a.nby, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
+    if (tune_nt()) launch_packed_t<true, false>(b, sample_bytes, chroma, mode, grid, block, stream);
+    else launch_packed_t<false, false>(b, sample_bytes, chroma, mode, grid, block, stream);
     return hipGetLastError();
 }
