@@ -25,6 +25,7 @@ struct DbkArgs {
     /* row-major block numbering of the packed kernels (filled by dbk_launch_packed) */
     int nb_total, wpf;              /* blocks per frame, workgroups per frame */
     uint32_t magic_wpf, magic_nbx;  /* floor(2^32/d)+1 reciprocals */
+    int xcd_swizzle;                /* renumber workgroups so each XCD gets a contiguous range */
     int diag_xshift; /* diagnostic copy mode only: byte shift of every row span (alignment experiments) */
 };
 

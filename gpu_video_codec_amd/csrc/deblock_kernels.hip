@@ -330,7 +330,7 @@ __device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
         return true;
     } else {
         const uint32_t id = blockIdx.x, per_xcd = gridDim.x >> 3;
-        const uint32_t logical = (id & 7u) * per_xcd + (id >> 3);
+        const uint32_t logical = a.xcd_swizzle ? (id & 7u) * per_xcd + (id >> 3) : id;
         const uint32_t f = __umulhi(logical, a.magic_wpf);
         if (f >= (uint32_t)a.n_frames) return false; /* padding workgroup */
         c.f = (int)f;
@@ -443,11 +443,17 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
     const long long wpf = (nb + wg - 1) / wg;
     const long long total = (wpf * a.n_frames + 7) / 8 * 8; /* multiple of 8: one contiguous range per XCD */
     /* reciprocal division floor(2^32/d)+1 is exact for dividends < 2^32/d and needs d >= 2 */
-    const bool linear = !tune_rowmap() && wpf >= 2 && a.nbx >= 2 && (nb + 1024) * a.nbx < (1ll << 32) &&
+    /* measured on MI355X: when a whole block row fits one workgroup (4K: 481 blocks) the row mapping wins
+     * (3.96 vs 3.69 TB/s at 4K 8-bit, idle lanes included); wider rows (8K: 961 blocks) do better row-major
+     * (5.06 vs 4.89 TB/s at 8K 10-bit).  HEVCDBK_TUNE=rowmap / linear force either for A/B runs. */
+    const char *tune = getenv("HEVCDBK_TUNE");
+    const bool want_linear = (tune && strstr(tune, "linear")) || (!tune_rowmap() && a.nbx > cap);
+    const bool linear = want_linear && wpf >= 2 && a.nbx >= 2 && (nb + 1024) * a.nbx < (1ll << 32) &&
                         total * wpf < (1ll << 32) && total < (1ll << 31);
     if (linear) {
         b.nb_total = (int)nb;
         b.wpf = (int)wpf;
+        { const char *e = getenv("HEVCDBK_TUNE"); b.xcd_swizzle = !(e && strstr(e, "noswz")); }
         b.magic_wpf = (uint32_t)((1ull << 32) / (unsigned long long)wpf + 1ull);
         b.magic_nbx = (uint32_t)((1ull << 32) / (unsigned long long)a.nbx + 1ull);
         dim3 block(wg, 1, 1), grid((unsigned)total, 1, 1);
