@@ -300,3 +300,26 @@ def test_error_codes_on_device(ctx, oracle):
     ctx.filter_device(p, 30)
     ctx.synchronize()
     b.free()
+
+
+def test_row_major_mapping_forced(ctx, oracle, monkeypatch):
+    """The row-major (linear) block mapping is chosen automatically only for rows wider than one
+    workgroup (8K); force it on small, ragged and multi-frame geometries as well."""
+    from gpu_video_codec_amd import synth, _lib
+    monkeypatch.setenv("HEVCDBK_TUNE", "linear")
+    rng = np.random.default_rng(99)
+    for (w, h) in [(352, 288), (520, 136), (1032, 72), (3840, 64), (4104, 40)]:
+        frames = np.stack([synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30))) for _ in range(3)])
+        frames[1, : h // 2, : w // 3] = rng.integers(0, 256, (h // 2, w // 3), dtype=np.uint8)
+        bss = [oracle.lcg_bs(w, h, 5), oracle.default_bs(w, h), oracle.lcg_bs(w, h, 6)]
+        got = run_batch(ctx, frames, 37, variant=_lib.KERNEL_PACKED, bs=bss)
+        for f in range(3):
+            assert np.array_equal(got[f], oracle.filter_plane(frames[f], 37, vert_bs=bss[f][0], hor_bs=bss[f][1])), (w, h, f)
+        f10 = np.stack([synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30)), bit_depth=10) for _ in range(2)])
+        got = run_batch(ctx, f10, 32, variant=_lib.KERNEL_PACKED, bit_depth=10)
+        for f in range(2):
+            assert np.array_equal(got[f], oracle.filter_plane(f10[f], 32, bit_depth=10)), (w, h, f)
+        c = frames[:2]
+        got = run_batch(ctx, c, 40, variant=_lib.KERNEL_PACKED, is_chroma=True)
+        for f in range(2):
+            assert np.array_equal(got[f], oracle.filter_plane(c[f], 40, is_chroma=True)), (w, h, f)
