@@ -150,6 +150,37 @@ template <bool NT> constexpr int aux_bits() { return NT ? 2 : 0; }
 constexpr uint32_t kOob = 0xfffffff0u; /* voffset >= num_records: load returns 0, store is dropped */
 
 /*
+ * The four bS bytes of a lane's offset block (cpu.h:159-163, 223-227, 287-291, 368-372 and the chroma twins),
+ * as four back-to-back buffer_load_ubyte with NO wait in between.  The guards of the reference fold into
+ * the buffer range check wherever the failing index is out of the array: ver1 at by == 0 has a negative
+ * index, ver2 at by == nby-1 (and the chroma over-read) has index >= n_vert, hor2 past the array
+ * likewise -- the hardware returns 0 there.  Only "bx > 0" (hor1) and "bx < limit_bx" (hor2) can fail on an
+ * in-range index and need a select; interior waves (EDGE == false) satisfy both by construction.
+ */
+template <bool EDGE>
+__device__ __forceinline__ dbk::BlockBs load_bs_buffer(const DbkArgs &a, int f, int by, int bx, bool active)
+{
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.vert_bs) + (long long)f * a.vert_bs_stride, 0, (uint32_t)a.n_vert, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.hor_bs) + (long long)f * a.hor_bs_stride, 0, (uint32_t)a.n_hor, 0x00020000);
+    dbk::BlockBs b;
+    if constexpr (!EDGE) { /* by wave-uniform: scalar row offsets */
+        b.ver1 = __builtin_amdgcn_raw_buffer_load_b8(rv, (uint32_t)bx, (by - 1) * a.vstride, 0);
+        b.ver2 = __builtin_amdgcn_raw_buffer_load_b8(rv, (uint32_t)bx, by * a.vstride, 0);
+        b.hor1 = __builtin_amdgcn_raw_buffer_load_b8(rh, (uint32_t)(bx - 1), by * a.hstride, 0);
+        b.hor2 = __builtin_amdgcn_raw_buffer_load_b8(rh, (uint32_t)bx, by * a.hstride, 0);
+    } else {
+        const uint32_t iv = (uint32_t)(by * a.vstride + bx), ih = (uint32_t)(by * a.hstride + bx);
+        b.ver1 = __builtin_amdgcn_raw_buffer_load_b8(rv, active ? iv - (uint32_t)a.vstride : kOob, 0, 0);
+        b.ver2 = __builtin_amdgcn_raw_buffer_load_b8(rv, active ? iv : kOob, 0, 0);
+        b.hor1 = __builtin_amdgcn_raw_buffer_load_b8(rh, (active && bx > 0) ? ih - 1u : kOob, 0, 0);
+        b.hor2 = __builtin_amdgcn_raw_buffer_load_b8(rh, (active && bx < a.limit_bx) ? ih : kOob, 0, 0);
+    }
+    return b;
+}
+
+/*
  * Body of the packed kernel for one lane (= one offset block).
  *
  * EDGE == false: interior wave -- all 64 lanes own both halves of all 8 rows.  The 8 row loads are
@@ -197,11 +228,8 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
     }
 
     if constexpr (MODE == 0) {
-        dbk::BlockBs bs{0, 0, 0, 0};
-        if (!EDGE || active)
-            bs = dbk::load_block_bs(a.vert_bs + (long long)f * a.vert_bs_stride, a.hor_bs + (long long)f * a.hor_bs_stride,
-                                    bx, by, a.vstride, a.hstride, a.limit_bx, a.limit_by, a.n_vert, a.n_hor);
-        dbk::packed_filter_block<CHROMA>(L, R, bs, a.tc, a.beta);
+        const dbk::BlockBs bs = load_bs_buffer<EDGE>(a, f, by, bx, active);
+        dbk::packed_filter_block<CHROMA>(L, R, bs, a.tc, a.beta, a.diag_ablate);
     }
 
     if constexpr (!EDGE) {
@@ -268,10 +296,7 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
     }
 
     if constexpr (MODE == 0) {
-        dbk::BlockBs bs{0, 0, 0, 0};
-        if (!EDGE || active)
-            bs = dbk::load_block_bs(a.vert_bs + (long long)f * a.vert_bs_stride, a.hor_bs + (long long)f * a.hor_bs_stride,
-                                    bx, by, a.vstride, a.hstride, a.limit_bx, a.limit_by, a.n_vert, a.n_hor);
+        const dbk::BlockBs bs = load_bs_buffer<EDGE>(a, f, by, bx, active);
         dbk::packed_filter_luma_block16(W, bs, a.tc, a.beta, a.max_v);
     }
 
@@ -432,6 +457,7 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
 {
     if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
     DbkArgs b = a;
+    { const char *e = getenv("HEVCDBK_TUNE"); b.diag_ablate = e && strstr(e, "nostrong") ? 1 : (e && strstr(e, "nonormal") ? 2 : 0); }
     if (mode == 1) { /* diagnostic copy only: HEVCDBK_TUNE=align shifts the spans onto their natural alignment */
         const char *e = getenv("HEVCDBK_TUNE");
         b.diag_xshift = (e && strstr(e, "align")) ? 4 * sample_bytes : 0;
