@@ -26,6 +26,7 @@ struct DbkArgs {
     int nb_total, wpf;              /* blocks per frame, workgroups per frame */
     uint32_t magic_wpf, magic_nbx;  /* floor(2^32/d)+1 reciprocals */
     int xcd_swizzle;                /* renumber workgroups so each XCD gets a contiguous range */
+    int use_queue;   /* 8-bit luma: strong segments scheduled through the workgroup's LDS queue */
     int diag_ablate; /* diagnostic: 1 = strong segments filtered as normal, 2 = normal filter skipped (wrong pixels) */
     int diag_xshift; /* diagnostic copy mode only: byte shift of every row span (alignment experiments) */
 };

@@ -405,6 +405,252 @@ __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
     else packed_body<CHROMA, MODE, NT, true>(a, c.by, c.f, c.bx, c.active);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* 8-bit luma with workgroup-level scheduling of the strong filter                              */
+/*
+ * Why: strong (cpu.h:1128-1213) and normal (cpu.h:1215-1357) segments are mixed in every wave, so the
+ * plain kernel executes both paths for all 64 lanes; with either path removed it sits at the memory floor
+ * (DESIGN.md 4.1).  Here a lane that decides "strong" does not filter: it appends its 16 tap registers to
+ * a queue in LDS; after a workgroup barrier the queue is drained by consecutive lanes of the whole
+ * workgroup (strong path at ~100 % lane utilisation instead of ~26 %), a second barrier, and the owners
+ * read their 12 changed registers back.  Three stages follow the data dependences: ver1+ver2 (independent
+ * of each other), hor1, hor2.  A segment that does not fit the queue is filtered inline (same result).
+ *
+ * LDS: one array, two queue regions used alternately (stage V and H2 -> region 0, H1 -> region 1; a wave
+ * can only reach the H2 push after every wave has finished reading stage V back) + three tail counters.
+ * Each region is 4 planes of uint4 (structure of arrays: consecutive slots are consecutive 16-byte words,
+ * conflict-free for ds_read/write_b128):
+ *   plane 0 = a.p0,a.p1,a.p2,a.q0   plane 1 = a.q1,a.q2,b.p0,b.p1   plane 2 = b.p2,b.q0,b.q1,b.q2
+ *   plane 3 = a.p3,a.q3,b.p3,b.q3 (read-only inputs, never written back)
+ */
+constexpr int kQCap0 = 368, kQCap1 = 256;                       /* entries; 4 workgroups of 39,952 B fit 160 KiB */
+constexpr int kQWords = 4 * (kQCap0 + kQCap1) + 1;              /* uint4 words incl. the counters */
+
+struct QRegion {
+    uint4 *mem;
+    int cap;
+    unsigned *tail;
+};
+
+__device__ __forceinline__ void q_store_all(const QRegion &q, unsigned slot, const dbk::Taps &a, const dbk::Taps &b)
+{
+    using dbk::pk_bits;
+    q.mem[0 * q.cap + slot] = make_uint4(pk_bits(a.p0), pk_bits(a.p1), pk_bits(a.p2), pk_bits(a.q0));
+    q.mem[1 * q.cap + slot] = make_uint4(pk_bits(a.q1), pk_bits(a.q2), pk_bits(b.p0), pk_bits(b.p1));
+    q.mem[2 * q.cap + slot] = make_uint4(pk_bits(b.p2), pk_bits(b.q0), pk_bits(b.q1), pk_bits(b.q2));
+    q.mem[3 * q.cap + slot] = make_uint4(pk_bits(a.p3), pk_bits(a.q3), pk_bits(b.p3), pk_bits(b.q3));
+}
+__device__ __forceinline__ void q_store_results(const QRegion &q, unsigned slot, const dbk::Taps &a, const dbk::Taps &b)
+{
+    using dbk::pk_bits;
+    q.mem[0 * q.cap + slot] = make_uint4(pk_bits(a.p0), pk_bits(a.p1), pk_bits(a.p2), pk_bits(a.q0));
+    q.mem[1 * q.cap + slot] = make_uint4(pk_bits(a.q1), pk_bits(a.q2), pk_bits(b.p0), pk_bits(b.p1));
+    q.mem[2 * q.cap + slot] = make_uint4(pk_bits(b.p2), pk_bits(b.q0), pk_bits(b.q1), pk_bits(b.q2));
+}
+__device__ __forceinline__ void q_load_results(const QRegion &q, unsigned slot, dbk::Taps &a, dbk::Taps &b)
+{
+    using dbk::bits_pk;
+    const uint4 w0 = q.mem[0 * q.cap + slot], w1 = q.mem[1 * q.cap + slot], w2 = q.mem[2 * q.cap + slot];
+    a.p0 = bits_pk(w0.x); a.p1 = bits_pk(w0.y); a.p2 = bits_pk(w0.z); a.q0 = bits_pk(w0.w);
+    a.q1 = bits_pk(w1.x); a.q2 = bits_pk(w1.y); b.p0 = bits_pk(w1.z); b.p1 = bits_pk(w1.w);
+    b.p2 = bits_pk(w2.x); b.q0 = bits_pk(w2.y); b.q1 = bits_pk(w2.z); b.q2 = bits_pk(w2.w);
+}
+__device__ __forceinline__ void q_load_all(const QRegion &q, unsigned slot, dbk::Taps &a, dbk::Taps &b)
+{
+    using dbk::bits_pk;
+    q_load_results(q, slot, a, b);
+    const uint4 w3 = q.mem[3 * q.cap + slot];
+    a.p3 = bits_pk(w3.x); a.q3 = bits_pk(w3.y); b.p3 = bits_pk(w3.z); b.q3 = bits_pk(w3.w);
+}
+
+/* one stage: NS segments per lane (A[s], B[s] = pair A / pair B taps, on[s] = bS says "filter") */
+template <int NS>
+__device__ __forceinline__ void q_stage(dbk::Taps (&A)[NS], dbk::Taps (&B)[NS], const bool (&on)[NS], int beta, int tc,
+                                        const QRegion &q, int lane)
+{
+    bool strong[NS];
+    unsigned slot[NS];
+    unsigned wave_cnt = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        strong[s] = false;
+        if (on[s]) {
+            const dbk::Decision d = dbk::decide(A[s], beta, tc);
+            if (d.filter) {
+                if (d.strong) strong[s] = true;
+                else dbk::normal_pairs(A[s], B[s], tc, dbk::splat(d.cond5 ? -1 : 0), dbk::splat(d.cond6 ? -1 : 0), 255);
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(strong[s]);
+        slot[s] = wave_cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        wave_cnt += (unsigned)__builtin_popcountll(m);
+    }
+    /* one LDS atomic per wave reserves a contiguous run of slots */
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(q.tail, wave_cnt);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const dbk::pk c = dbk::splat(2 * tc);
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        slot[s] += base;
+        if (strong[s]) {
+            if (slot[s] < (unsigned)q.cap) {
+                q_store_all(q, slot[s], A[s], B[s]);
+            } else { /* queue full: filter here (rare; same arithmetic) */
+                dbk::strong_pair(A[s], c);
+                dbk::strong_pair(B[s], c);
+                strong[s] = false;
+            }
+        }
+    }
+    __syncthreads();
+    {   /* drain: lane tid of the workgroup takes queue entry tid */
+        unsigned total = *q.tail;
+        if (total > (unsigned)q.cap) total = (unsigned)q.cap;
+        for (unsigned e = threadIdx.x; e < total; e += blockDim.x) {
+            dbk::Taps ta, tb;
+            q_load_all(q, e, ta, tb);
+            dbk::strong_pair(ta, c);
+            dbk::strong_pair(tb, c);
+            q_store_results(q, e, ta, tb);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (strong[s]) q_load_results(q, slot[s], A[s], B[s]);
+}
+
+template <bool NT, bool LINEAR>
+__global__ __launch_bounds__(512) void dbk_packed_q_kernel(const DbkArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint4 smem[kQWords];
+    unsigned *tails = reinterpret_cast<unsigned *>(&smem[kQWords - 1]);
+    if (threadIdx.x < 3) tails[threadIdx.x] = 0u;
+
+    WaveCoords c;
+    if (!wave_coords<LINEAR>(a, c)) return; /* workgroup-uniform */
+    const int lane = (int)(threadIdx.x & 63u);
+    const int f = c.f, by = c.by, bx = c.bx;
+    const bool active = c.active;
+    const bool lv = active && bx > 0, rv = active && bx < a.nbx - 1;
+    const int y0 = by * 8 - 4;
+    const uint32_t xoff = (uint32_t)(bx * 8 - 4);
+    const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.src) + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        a.dst + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
+
+    uint32_t L[8], R[8];
+    dbk::BlockBs bs;
+    if (c.interior) {
+        const int by_s = __builtin_amdgcn_readfirstlane(by);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, (by_s * 8 - 4 + r) * (int)a.pitch, aux_bits<NT>());
+            L[r] = w.x;
+            R[r] = w.y;
+        }
+        bs = load_bs_buffer<false>(a, f, by_s, bx, true);
+    } else {
+        const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
+            const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
+            L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
+            R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && rv) ? off + 4u : kOob, 0, aux_bits<NT>());
+        }
+        bs = load_bs_buffer<true>(a, f, by, bx, active);
+    }
+
+    const QRegion q0{smem, kQCap0, &tails[0]};
+    const QRegion q1{smem + 4 * kQCap0, kQCap1, &tails[1]};
+    const QRegion q2{smem, kQCap0, &tails[2]};
+    __syncthreads(); /* counters zeroed before the first push */
+
+    using dbk::Taps;
+    using dbk::pick_hi;
+    using dbk::pick_lo;
+    /* stage V: ver1 and ver2 (cpu.h:159-284) */
+    Taps VA[2] = {dbk::unpack_ver(L[0], L[3], R[0], R[3]), dbk::unpack_ver(L[4], L[7], R[4], R[7])};
+    Taps VB[2] = {dbk::unpack_ver(L[1], L[2], R[1], R[2]), dbk::unpack_ver(L[5], L[6], R[5], R[6])};
+    {
+        const bool on[2] = {bs.ver1 > 0, bs.ver2 > 0};
+        q_stage<2>(VA, VB, on, a.beta, a.tc, q0, lane);
+    }
+    const Taps &va1 = VA[0], &vb1 = VB[0], &va2 = VA[1], &vb2 = VB[1];
+
+    /* stage H1 (cpu.h:287-365); register re-pairing as in dbk::luma_block_core */
+    Taps HA[1], HB[1];
+    Taps &ha = HA[0], &hb = HB[0];
+    ha.p0 = pick_hi(va1.p3, va1.p0); hb.p0 = pick_hi(va1.p2, va1.p1);
+    ha.p1 = pick_hi(vb1.p3, vb1.p0); hb.p1 = pick_hi(vb1.p2, vb1.p1);
+    ha.p2 = pick_lo(vb1.p3, vb1.p0); hb.p2 = pick_lo(vb1.p2, vb1.p1);
+    ha.p3 = pick_lo(va1.p3, va1.p0); hb.p3 = pick_lo(va1.p2, va1.p1);
+    ha.q0 = pick_lo(va2.p3, va2.p0); hb.q0 = pick_lo(va2.p2, va2.p1);
+    ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1);
+    ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1);
+    ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1);
+    {
+        const bool on[1] = {bs.hor1 > 0};
+        q_stage<1>(HA, HB, on, a.beta, a.tc, q1, lane);
+    }
+
+    /* stage H2 (cpu.h:368-446) */
+    Taps GA[1], GB[1];
+    Taps &ga = GA[0], &gb = GB[0];
+    ga.p0 = pick_hi(va1.q0, va1.q3); gb.p0 = pick_hi(va1.q1, va1.q2);
+    ga.p1 = pick_hi(vb1.q0, vb1.q3); gb.p1 = pick_hi(vb1.q1, vb1.q2);
+    ga.p2 = pick_lo(vb1.q0, vb1.q3); gb.p2 = pick_lo(vb1.q1, vb1.q2);
+    ga.p3 = pick_lo(va1.q0, va1.q3); gb.p3 = pick_lo(va1.q1, va1.q2);
+    ga.q0 = ha.q0; ga.q1 = ha.q1; ga.q2 = ha.q2; ga.q3 = ha.q3;
+    gb.q0 = hb.q0; gb.q1 = hb.q1; gb.q2 = hb.q2; gb.q3 = hb.q3;
+    {
+        const bool on[1] = {bs.hor2 > 0};
+        q_stage<1>(GA, GB, on, a.beta, a.tc, q2, lane);
+    }
+
+    /* final pack (as dbk::packed_filter_luma_block) */
+    using dbk::row_of;
+    using dbk::perm;
+    using dbk::pk_bits;
+    L[0] = row_of(ha.p3, hb.p3); L[1] = row_of(ha.p2, hb.p2); L[2] = row_of(ha.p1, hb.p1); L[3] = row_of(ha.p0, hb.p0);
+    L[4] = row_of(ga.q0, gb.q0); L[5] = row_of(ga.q1, gb.q1); L[6] = row_of(ga.q2, gb.q2); L[7] = row_of(ga.q3, gb.q3);
+    R[0] = row_of(ga.p3, gb.p3); R[1] = row_of(ga.p2, gb.p2); R[2] = row_of(ga.p1, gb.p1); R[3] = row_of(ga.p0, gb.p0);
+    {
+        const uint32_t u1 = perm(pk_bits(va2.q1), pk_bits(va2.q0), 0x06020400u);
+        const uint32_t u2 = perm(pk_bits(va2.q3), pk_bits(va2.q2), 0x06020400u);
+        R[4] = perm(u2, u1, 0x05040100u);
+        R[7] = perm(u2, u1, 0x07060302u);
+        const uint32_t w1 = perm(pk_bits(vb2.q1), pk_bits(vb2.q0), 0x06020400u);
+        const uint32_t w2 = perm(pk_bits(vb2.q3), pk_bits(vb2.q2), 0x06020400u);
+        R[5] = perm(w2, w1, 0x05040100u);
+        R[6] = perm(w2, w1, 0x07060302u);
+    }
+
+    if (c.interior) {
+        const int by_s = __builtin_amdgcn_readfirstlane(by);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            u32x2 w;
+            w.x = L[r];
+            w.y = R[r];
+            __builtin_amdgcn_raw_buffer_store_b64(w, rd, xoff, (by_s * 8 - 4 + r) * (int)a.pitch, aux_bits<NT>());
+        }
+    } else {
+        const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
+            const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
+            __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, (yv && rv) ? off + 4u : kOob, 0, aux_bits<NT>());
+        }
+    }
+}
+
 } /* namespace */
 
 bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
@@ -445,7 +691,9 @@ static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int
     if (sample_bytes == 2) {
         if (mode == 1) hipLaunchKernelGGL((dbk_packed16_kernel<1, NT, LINEAR>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR>), grid, block, 0, stream, a);
-    } else if (mode == 1)
+    } else if (mode == 0 && !chroma && a.use_queue && block.x <= 512)
+        hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR>), grid, block, 0, stream, a);
+    else if (mode == 1)
         hipLaunchKernelGGL((dbk_packed_kernel<false, 1, NT, LINEAR>), grid, block, 0, stream, a);
     else if (chroma)
         hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT, LINEAR>), grid, block, 0, stream, a);
@@ -457,7 +705,8 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
 {
     if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
     DbkArgs b = a;
-    { const char *e = getenv("HEVCDBK_TUNE"); b.diag_ablate = e && strstr(e, "nostrong") ? 1 : (e && strstr(e, "nonormal") ? 2 : 0); }
+    { const char *e = getenv("HEVCDBK_TUNE"); b.diag_ablate = e && strstr(e, "nostrong") ? 1 : (e && strstr(e, "nonormal") ? 2 : (e && strstr(e, "barriers") ? 4 : 0)); }
+    { const char *e = getenv("HEVCDBK_TUNE"); b.use_queue = (e && strstr(e, "queue")) ? 1 : 0; }
     if (mode == 1) { /* diagnostic copy only: HEVCDBK_TUNE=align shifts the spans onto their natural alignment */
         const char *e = getenv("HEVCDBK_TUNE");
         b.diag_xshift = (e && strstr(e, "align")) ? 4 * sample_bytes : 0;

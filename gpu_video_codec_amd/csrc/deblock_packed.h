@@ -375,6 +375,20 @@ DBK_HD pk pick_lo(pk x, pk y) { return bits_pk(perm(pk_bits(y), pk_bits(x), 0x05
 DBK_HD pk pick_hi(pk x, pk y) { return bits_pk(perm(pk_bits(y), pk_bits(x), 0x07060302u)); } /* (x.hi, y.hi) */
 DBK_HD uint32_t row_of(pk a, pk b) { return perm(pk_bits(b), pk_bits(a), 0x02060400u); }     /* [a.lo, b.lo, b.hi, a.hi] */
 
+/* diagnostic only (ablate == 4): two workgroup barriers per stage, to price the synchronisation a
+ * workgroup-level exchange between the stages would need */
+DBK_HD void diag_barriers(int ablate)
+{
+#if DBK_DEV
+    if (ablate == 4) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+    }
+#else
+    (void)ablate;
+#endif
+}
+
 /* the four segments on already-unpacked ver registers; leaves the final values in
  * ha/hb (cols 0..3 of rows 0..3 as P, taps p3..p0), ga/gb (P = cols 4..7 of rows 0..3, Q = cols 0..3 of
  * rows 4..7) and va2/vb2 q taps (cols 4..7 of rows 4..7) */
@@ -383,6 +397,7 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
 {
     if (bs.ver1 > 0) luma_pairs(va1, vb1, beta, tc, max_v, ablate); /* cpu.h:164 */
     if (bs.ver2 > 0) luma_pairs(va2, vb2, beta, tc, max_v, ablate); /* cpu.h:228 */
+    diag_barriers(ablate);
 
     /* hor1: lines = cols 0..3, pair A = cols (0,3) = ver taps (p3,p0), pair B = cols (1,2) = (p2,p1);
      * P_k = row 3-k, Q_k = row 4+k (cpu.h:287-365) */
@@ -395,6 +410,7 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
     ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1); /* row 6 */
     ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1); /* row 7 */
     if (bs.hor1 > 0) luma_pairs(ha, hb, beta, tc, max_v, ablate); /* cpu.h:292 */
+    diag_barriers(ablate);
 
     /* hor2: P lines = cols 4..7 (ver taps q0..q3) of rows 3..0, pair A = cols (4,7), B = cols (5,6);
      * Q = the same registers hor1 just used for its Q side: cols 0..3 of rows 4..7 (cpu.h:368-446) */
@@ -405,6 +421,7 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
     ga.q0 = ha.q0; ga.q1 = ha.q1; ga.q2 = ha.q2; ga.q3 = ha.q3;
     gb.q0 = hb.q0; gb.q1 = hb.q1; gb.q2 = hb.q2; gb.q3 = hb.q3;
     if (bs.hor2 > 0) luma_pairs(ga, gb, beta, tc, max_v, ablate); /* cpu.h:373 */
+    diag_barriers(ablate);
 }
 
 /* 8-bit samples: L[r] = cols 0..3, R[r] = cols 4..7 of row r as bytes */
