@@ -423,8 +423,12 @@ __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
  *   plane 0 = a.p0,a.p1,a.p2,a.q0   plane 1 = a.q1,a.q2,b.p0,b.p1   plane 2 = b.p2,b.q0,b.q1,b.q2
  *   plane 3 = a.p3,a.q3,b.p3,b.q3 (read-only inputs, never written back)
  */
-constexpr int kQCap0 = 368, kQCap1 = 256;                       /* entries; 4 workgroups of 39,952 B fit 160 KiB */
-constexpr int kQWords = 4 * (kQCap0 + kQCap1) + 1;              /* uint4 words incl. the counters */
+/* queue capacities per workgroup width WG (threads): stage V pushes up to 2*WG candidates, H1/H2 up to WG;
+ * sized for ~36 % / 50 % strong, overflow is filtered inline.  WG=512: 39,952 B (4 workgroups per CU). */
+template <int WG> struct QCaps {
+    static constexpr int cap0 = WG * 23 / 32, cap1 = WG / 2;
+    static constexpr int words = 4 * (cap0 + cap1) + 1; /* uint4 words incl. the counters */
+};
 
 struct QRegion {
     uint4 *mem;
@@ -521,9 +525,10 @@ __device__ __forceinline__ void q_stage(dbk::Taps (&A)[NS], dbk::Taps (&B)[NS], 
         if (strong[s]) q_load_results(q, slot[s], A[s], B[s]);
 }
 
-template <bool NT, bool LINEAR>
-__global__ __launch_bounds__(512) void dbk_packed_q_kernel(const DbkArgs a)
+template <bool NT, bool LINEAR, int WG>
+__global__ __launch_bounds__(WG) void dbk_packed_q_kernel(const DbkArgs a)
 {
+    constexpr int kQCap0 = QCaps<WG>::cap0, kQCap1 = QCaps<WG>::cap1, kQWords = QCaps<WG>::words;
     __shared__ __attribute__((aligned(16))) uint4 smem[kQWords];
     unsigned *tails = reinterpret_cast<unsigned *>(&smem[kQWords - 1]);
     if (threadIdx.x < 3) tails[threadIdx.x] = 0u;
@@ -691,8 +696,11 @@ static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int
     if (sample_bytes == 2) {
         if (mode == 1) hipLaunchKernelGGL((dbk_packed16_kernel<1, NT, LINEAR>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR>), grid, block, 0, stream, a);
-    } else if (mode == 0 && !chroma && a.use_queue && block.x <= 512)
-        hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR>), grid, block, 0, stream, a);
+    } else if (mode == 0 && !chroma && a.use_queue && block.x <= 512) {
+        if (block.x <= 128) hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 128>), grid, block, 0, stream, a);
+        else if (block.x <= 256) hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 256>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 512>), grid, block, 0, stream, a);
+    }
     else if (mode == 1)
         hipLaunchKernelGGL((dbk_packed_kernel<false, 1, NT, LINEAR>), grid, block, 0, stream, a);
     else if (chroma)

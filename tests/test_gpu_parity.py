@@ -323,3 +323,21 @@ def test_row_major_mapping_forced(ctx, oracle, monkeypatch):
         got = run_batch(ctx, c, 40, variant=_lib.KERNEL_PACKED, is_chroma=True)
         for f in range(2):
             assert np.array_equal(got[f], oracle.filter_plane(c[f], 40, is_chroma=True)), (w, h, f)
+
+
+def test_lds_queue_variant_is_bit_exact(ctx, oracle, monkeypatch):
+    """HEVCDBK_TUNE=queue selects the experimental 8-bit luma kernel that schedules strong segments through
+    a workgroup LDS queue: same bytes, including queue overflow (an all-flat frame makes every
+    segment strong) and planes narrower than a workgroup."""
+    from gpu_video_codec_amd import synth, _lib
+    monkeypatch.setenv("HEVCDBK_TUNE", "queue")
+    flat = np.full((96, 4096), 100, np.uint8)
+    flat[:, 2048:] += 4          # mild steps on every 8x8 edge: strong filter everywhere -> queue overflows
+    flat[::16] += 2
+    frames = {"synth": synth.blocky_plane(3840, 72, seed=8), "flat": flat,
+              "narrow": synth.blocky_plane(200, 64, seed=9), "noise": np.random.default_rng(1).integers(0, 256, (64, 1032), dtype=np.uint8)}
+    for name, y in frames.items():
+        for qp in (32, 45):
+            got = run_batch(ctx, np.stack([y, y[::-1]]), qp, variant=_lib.KERNEL_PACKED)
+            assert np.array_equal(got[0], oracle.filter_plane(y, qp)), (name, qp)
+            assert np.array_equal(got[1], oracle.filter_plane(y[::-1], qp)), (name, qp)
