@@ -180,6 +180,32 @@ __device__ __forceinline__ dbk::BlockBs load_bs_buffer(const DbkArgs &a, int f, 
     return b;
 }
 
+/* per-segment tc / beta of a lane's block: the scalar-QP values, or -- QPMAP -- looked up from the per-CTU
+ * map exactly as the generic kernel and the oracle do (QP = (QpP + QpQ + 1) >> 1 of the CTUs holding P0 / Q0
+ * of the segment's first line) */
+template <bool QPMAP, bool CHROMA>
+__device__ __forceinline__ dbk::BlockQp block_qp(const DbkArgs &a, int f, int by, int bx)
+{
+    dbk::BlockQp q;
+    if constexpr (QPMAP) {
+        const uint8_t *map = a.qp_map + (long long)f * a.map_frame_stride;
+        const int sc = CHROMA ? 2 : 1, lw = a.plane_w * sc, lh = a.plane_h * sc;
+        const int x0 = bx * 8 - 4, y0 = by * 8 - 4;
+        const int qp0 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 3, y0 + 0, x0 + 4, y0 + 0);
+        const int qp1 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 3, y0 + 4, x0 + 4, y0 + 4);
+        const int qp2 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 0, y0 + 3, x0 + 0, y0 + 4);
+        const int qp3 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 4, y0 + 3, x0 + 0, y0 + 4);
+        q.tc[0] = a.tc_tab[qp0] << a.shift; q.beta[0] = a.beta_tab[qp0] << a.shift;
+        q.tc[1] = a.tc_tab[qp1] << a.shift; q.beta[1] = a.beta_tab[qp1] << a.shift;
+        q.tc[2] = a.tc_tab[qp2] << a.shift; q.beta[2] = a.beta_tab[qp2] << a.shift;
+        q.tc[3] = a.tc_tab[qp3] << a.shift; q.beta[3] = a.beta_tab[qp3] << a.shift;
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++) { q.tc[s] = a.tc; q.beta[s] = a.beta; }
+    }
+    return q;
+}
+
 /*
  * Body of the packed kernel for one lane (= one offset block).
  *
@@ -192,7 +218,7 @@ __device__ __forceinline__ dbk::BlockBs load_bs_buffer(const DbkArgs &a, int f, 
  *   with wave-uniform branches.
  * MODE 0 = filter, MODE 1 = diagnostic copy (same loads/stores, no arithmetic).
  */
-template <bool CHROMA, int MODE, bool NT, bool EDGE>
+template <bool CHROMA, int MODE, bool NT, bool EDGE, bool QPMAP>
 __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int bx, bool active)
 {
     /* EDGE == false: by is wave-uniform (scalar row offsets); EDGE == true: by and bx may differ per lane */
@@ -229,7 +255,8 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
 
     if constexpr (MODE == 0) {
         const dbk::BlockBs bs = load_bs_buffer<EDGE>(a, f, by, bx, active);
-        dbk::packed_filter_block<CHROMA>(L, R, bs, a.tc, a.beta, a.diag_ablate);
+        const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
+        dbk::packed_filter_block<CHROMA>(L, R, bs, q, a.diag_ablate);
     }
 
     if constexpr (!EDGE) {
@@ -262,7 +289,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
  * they are (no widening needed), so twice the bytes per pixel at the same instruction count: this is
  * the variant that runs into the HBM roof (BASELINE config 5).
  */
-template <int MODE, bool NT, bool EDGE>
+template <int MODE, bool NT, bool EDGE, bool QPMAP>
 __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, int bx, bool active)
 {
     const bool lv = active && bx > 0;
@@ -297,7 +324,8 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
 
     if constexpr (MODE == 0) {
         const dbk::BlockBs bs = load_bs_buffer<EDGE>(a, f, by, bx, active);
-        dbk::packed_filter_luma_block16(W, bs, a.tc, a.beta, a.max_v);
+        const dbk::BlockQp q = block_qp<QPMAP, false>(a, f, by, active ? bx : 0);
+        dbk::packed_filter_luma_block16(W, bs, q, a.max_v);
     }
 
     if constexpr (!EDGE) {
@@ -378,13 +406,13 @@ __device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
     }
 }
 
-template <int MODE, bool NT, bool LINEAR>
+template <int MODE, bool NT, bool LINEAR, bool QPMAP>
 __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
 {
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
-    if (c.interior) packed16_body<MODE, NT, false>(a, c.by, c.f, c.bx, true);
-    else packed16_body<MODE, NT, true>(a, c.by, c.f, c.bx, c.active);
+    if (c.interior) packed16_body<MODE, NT, false, QPMAP>(a, c.by, c.f, c.bx, true);
+    else packed16_body<MODE, NT, true, QPMAP>(a, c.by, c.f, c.bx, c.active);
 }
 
 /*
@@ -396,13 +424,13 @@ __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
  * both halves of every such line on one CU / one XCD L2, where the partial writes merge before
  * write-back.
  */
-template <bool CHROMA, int MODE, bool NT, bool LINEAR>
+template <bool CHROMA, int MODE, bool NT, bool LINEAR, bool QPMAP>
 __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
 {
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
-    if (c.interior) packed_body<CHROMA, MODE, NT, false>(a, c.by, c.f, c.bx, true);
-    else packed_body<CHROMA, MODE, NT, true>(a, c.by, c.f, c.bx, c.active);
+    if (c.interior) packed_body<CHROMA, MODE, NT, false, QPMAP>(a, c.by, c.f, c.bx, true);
+    else packed_body<CHROMA, MODE, NT, true, QPMAP>(a, c.by, c.f, c.bx, c.active);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -660,7 +688,6 @@ __global__ __launch_bounds__(WG) void dbk_packed_q_kernel(const DbkArgs a)
 
 bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
 {
-    if (a.qp_map != nullptr) return false;                       /* scalar QP only */
     if (sample_bytes == 1) return a.max_v == 255;                /* 8-bit: luma and chroma */
     /* 16-bit containers: luma, and only while every intermediate fits int16: the normal filter's
      * 9*(q0-p0) - 3*(q1-p1) + 8 needs 12*max_v + 8 <= 32767, i.e. bit depth <= 11 */
@@ -693,20 +720,24 @@ static bool tune_rowmap()
 template <bool NT, bool LINEAR>
 static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int mode, dim3 grid, dim3 block, hipStream_t stream)
 {
+    const bool qm = a.qp_map != nullptr;
     if (sample_bytes == 2) {
-        if (mode == 1) hipLaunchKernelGGL((dbk_packed16_kernel<1, NT, LINEAR>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR>), grid, block, 0, stream, a);
-    } else if (mode == 0 && !chroma && a.use_queue && block.x <= 512) {
+        if (mode == 1) hipLaunchKernelGGL((dbk_packed16_kernel<1, NT, LINEAR, false>), grid, block, 0, stream, a);
+        else if (qm) hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, false>), grid, block, 0, stream, a);
+    } else if (mode == 0 && !chroma && !qm && a.use_queue && block.x <= 512) {
         if (block.x <= 128) hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 128>), grid, block, 0, stream, a);
         else if (block.x <= 256) hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 256>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 512>), grid, block, 0, stream, a);
+    } else if (mode == 1)
+        hipLaunchKernelGGL((dbk_packed_kernel<false, 1, NT, LINEAR, false>), grid, block, 0, stream, a);
+    else if (chroma) {
+        if (qm) hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT, LINEAR, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT, LINEAR, false>), grid, block, 0, stream, a);
+    } else {
+        if (qm) hipLaunchKernelGGL((dbk_packed_kernel<false, 0, NT, LINEAR, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((dbk_packed_kernel<false, 0, NT, LINEAR, false>), grid, block, 0, stream, a);
     }
-    else if (mode == 1)
-        hipLaunchKernelGGL((dbk_packed_kernel<false, 1, NT, LINEAR>), grid, block, 0, stream, a);
-    else if (chroma)
-        hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT, LINEAR>), grid, block, 0, stream, a);
-    else
-        hipLaunchKernelGGL((dbk_packed_kernel<false, 0, NT, LINEAR>), grid, block, 0, stream, a);
 }
 
 hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, int mode, hipStream_t stream)

@@ -392,11 +392,11 @@ DBK_HD void diag_barriers(int ablate)
 /* the four segments on already-unpacked ver registers; leaves the final values in
  * ha/hb (cols 0..3 of rows 0..3 as P, taps p3..p0), ga/gb (P = cols 4..7 of rows 0..3, Q = cols 0..3 of
  * rows 4..7) and va2/vb2 q taps (cols 4..7 of rows 4..7) */
-DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const BlockBs &bs, int tc, int beta,
+DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const BlockBs &bs, const BlockQp &q,
                             int max_v, Taps &ha, Taps &hb, Taps &ga, Taps &gb, int ablate = 0)
 {
-    if (bs.ver1 > 0) luma_pairs(va1, vb1, beta, tc, max_v, ablate); /* cpu.h:164 */
-    if (bs.ver2 > 0) luma_pairs(va2, vb2, beta, tc, max_v, ablate); /* cpu.h:228 */
+    if (bs.ver1 > 0) luma_pairs(va1, vb1, q.beta[0], q.tc[0], max_v, ablate); /* cpu.h:164 */
+    if (bs.ver2 > 0) luma_pairs(va2, vb2, q.beta[1], q.tc[1], max_v, ablate); /* cpu.h:228 */
     diag_barriers(ablate);
 
     /* hor1: lines = cols 0..3, pair A = cols (0,3) = ver taps (p3,p0), pair B = cols (1,2) = (p2,p1);
@@ -409,7 +409,7 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
     ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1); /* row 5 */
     ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1); /* row 6 */
     ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1); /* row 7 */
-    if (bs.hor1 > 0) luma_pairs(ha, hb, beta, tc, max_v, ablate); /* cpu.h:292 */
+    if (bs.hor1 > 0) luma_pairs(ha, hb, q.beta[2], q.tc[2], max_v, ablate); /* cpu.h:292 */
     diag_barriers(ablate);
 
     /* hor2: P lines = cols 4..7 (ver taps q0..q3) of rows 3..0, pair A = cols (4,7), B = cols (5,6);
@@ -420,17 +420,17 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
     ga.p3 = pick_lo(va1.q0, va1.q3); gb.p3 = pick_lo(va1.q1, va1.q2); /* row 0 */
     ga.q0 = ha.q0; ga.q1 = ha.q1; ga.q2 = ha.q2; ga.q3 = ha.q3;
     gb.q0 = hb.q0; gb.q1 = hb.q1; gb.q2 = hb.q2; gb.q3 = hb.q3;
-    if (bs.hor2 > 0) luma_pairs(ga, gb, beta, tc, max_v, ablate); /* cpu.h:373 */
+    if (bs.hor2 > 0) luma_pairs(ga, gb, q.beta[3], q.tc[3], max_v, ablate); /* cpu.h:373 */
     diag_barriers(ablate);
 }
 
 /* 8-bit samples: L[r] = cols 0..3, R[r] = cols 4..7 of row r as bytes */
-DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, int tc, int beta, int ablate = 0)
+DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, const BlockQp &q, int ablate = 0)
 {
     Taps va1 = unpack_ver(L[0], L[3], R[0], R[3]), vb1 = unpack_ver(L[1], L[2], R[1], R[2]);
     Taps va2 = unpack_ver(L[4], L[7], R[4], R[7]), vb2 = unpack_ver(L[5], L[6], R[5], R[6]);
     Taps ha, hb, ga, gb;
-    luma_block_core(va1, vb1, va2, vb2, bs, tc, beta, 255, ha, hb, ga, gb, ablate);
+    luma_block_core(va1, vb1, va2, vb2, bs, q, 255, ha, hb, ga, gb, ablate);
 
     /* final pack, once per row dword */
     L[0] = row_of(ha.p3, hb.p3); L[1] = row_of(ha.p2, hb.p2); L[2] = row_of(ha.p1, hb.p1); L[3] = row_of(ha.p0, hb.p0);
@@ -461,12 +461,12 @@ DBK_HD Taps unpack_ver16(const uint32_t (&a)[4], const uint32_t (&b)[4])
     return t;
 }
 
-DBK_HD void packed_filter_luma_block16(uint32_t (&W)[8][4], const BlockBs &bs, int tc, int beta, int max_v)
+DBK_HD void packed_filter_luma_block16(uint32_t (&W)[8][4], const BlockBs &bs, const BlockQp &q, int max_v)
 {
     Taps va1 = unpack_ver16(W[0], W[3]), vb1 = unpack_ver16(W[1], W[2]);
     Taps va2 = unpack_ver16(W[4], W[7]), vb2 = unpack_ver16(W[5], W[6]);
     Taps ha, hb, ga, gb;
-    luma_block_core(va1, vb1, va2, vb2, bs, tc, beta, max_v, ha, hb, ga, gb);
+    luma_block_core(va1, vb1, va2, vb2, bs, q, max_v, ha, hb, ga, gb);
 
     /* pair A = cols (0,3) / (4,7), pair B = cols (1,2) / (5,6):  (c0,c1) = (A.lo,B.lo), (c2,c3) = (B.hi,A.hi) */
 #define DBK_ROW16(r, A, B, j)                                 \
@@ -485,15 +485,15 @@ DBK_HD void packed_filter_luma_block16(uint32_t (&W)[8][4], const BlockBs &bs, i
 
 /* ---- the whole block: ver1 -> ver2 -> hor1 -> hor2 --------------------------------------- */
 template <bool CHROMA>
-DBK_HD void packed_filter_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, int tc, int beta, int ablate = 0)
+DBK_HD void packed_filter_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, const BlockQp &q, int ablate = 0)
 {
     if constexpr (CHROMA) {
-        if (bs.ver1 == 2) chroma_ver<0>(L, R, tc);
-        if (bs.ver2 == 2) chroma_ver<4>(L, R, tc);
-        if (bs.hor1 == 2) chroma_hor(L, L, tc);
-        if (bs.hor2 == 2) chroma_hor(R, L, tc);
+        if (bs.ver1 == 2) chroma_ver<0>(L, R, q.tc[0]);
+        if (bs.ver2 == 2) chroma_ver<4>(L, R, q.tc[1]);
+        if (bs.hor1 == 2) chroma_hor(L, L, q.tc[2]);
+        if (bs.hor2 == 2) chroma_hor(R, L, q.tc[3]);
     } else {
-        packed_filter_luma_block(L, R, bs, tc, beta, ablate);
+        packed_filter_luma_block(L, R, bs, q, ablate);
     }
 }
 

@@ -62,12 +62,12 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
                 for (int s = 0; s < 4; s++) { q.tc[s] = tc; q.beta[s] = beta; }
             }
 #if HAVE_PACKED
-            if (packed && sizeof(T) == 2 && !is_chroma && !map) {
+            if (packed && sizeof(T) == 2 && !is_chroma) {
                 /* 16-bit containers through the packed core (luma, scalar QP) */
                 uint32_t W[8][4];
                 for (int r = 0; r < 8; r++)
                     for (int j = 0; j < 4; j++) W[r][j] = (uint32_t)v[r][2 * j] | ((uint32_t)v[r][2 * j + 1] << 16);
-                dbk::packed_filter_luma_block16(W, bs, tc, beta, max_v);
+                dbk::packed_filter_luma_block16(W, bs, q, max_v);
                 for (int r = 0; r < 8; r++)
                     for (int j = 0; j < 4; j++) {
                         v[r][2 * j] = W[r][j] & 0xffff;
@@ -82,8 +82,8 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
                     L[r] = (uint32_t)v[r][0] | ((uint32_t)v[r][1] << 8) | ((uint32_t)v[r][2] << 16) | ((uint32_t)v[r][3] << 24);
                     R[r] = (uint32_t)v[r][4] | ((uint32_t)v[r][5] << 8) | ((uint32_t)v[r][6] << 16) | ((uint32_t)v[r][7] << 24);
                 }
-                if (is_chroma) dbk::packed_filter_block<true>(L, R, bs, tc, beta);
-                else dbk::packed_filter_block<false>(L, R, bs, tc, beta);
+                if (is_chroma) dbk::packed_filter_block<true>(L, R, bs, q);
+                else dbk::packed_filter_block<false>(L, R, bs, q);
                 for (int r = 0; r < 8; r++)
                     for (int c = 0; c < 4; c++) {
                         v[r][c] = (L[r] >> (8 * c)) & 0xff;

@@ -187,11 +187,17 @@ def test_config3_image2_random_bs_and_ctu_qp_map(ctx, oracle, golden_inputs):
         for variant in variants(ctx):
             got = run_batch(ctx, y[None], qp, variant=variant, bs=[(vb, hb)])
             assert np.array_equal(got[0], oracle.filter_plane(y, qp, vert_bs=vb, hor_bs=hb))
+    for lo, hi, seed in ((22, 42, 7), (0, 51, 8)):
+        qmap = synth.ctu_qp_map(768, 576, seed=seed, lo=lo, hi=hi)
+        for variant in (_lib.KERNEL_GENERIC, _lib.KERNEL_PACKED, _lib.KERNEL_AUTO):  # per-lane tc/beta in both kernels
+            got = run_batch(ctx, y[None], 0, variant=variant, bs=[(vb, hb)], qp_map=qmap)
+            assert np.array_equal(got[0], oracle.filter_plane(y, 0, vert_bs=vb, hor_bs=hb, qp_map=qmap)), (variant, lo)
+            got = run_batch(ctx, u[None], 0, variant=variant, is_chroma=True, qp_map=qmap)
+            assert np.array_equal(got[0], oracle.filter_plane(u, 0, is_chroma=True, qp_map=qmap)), (variant, lo)
+        y10 = synth.blocky_plane(768, 576, seed=11, bit_depth=10)
+        got = run_batch(ctx, y10[None], 0, variant=_lib.KERNEL_PACKED, bit_depth=10, qp_map=qmap)
+        assert np.array_equal(got[0], oracle.filter_plane(y10, 0, bit_depth=10, qp_map=qmap)), lo
     qmap = synth.ctu_qp_map(768, 576, seed=7)
-    got = run_batch(ctx, y[None], 0, variant=_lib.KERNEL_AUTO, bs=[(vb, hb)], qp_map=qmap)
-    assert np.array_equal(got[0], oracle.filter_plane(y, 0, vert_bs=vb, hor_bs=hb, qp_map=qmap))
-    got = run_batch(ctx, u[None], 0, variant=_lib.KERNEL_AUTO, is_chroma=True, qp_map=qmap)
-    assert np.array_equal(got[0], oracle.filter_plane(u, 0, is_chroma=True, qp_map=qmap))
     # constant map == scalar QP (the pinned degenerate case)
     got = run_batch(ctx, y[None], 0, variant=_lib.KERNEL_AUTO, qp_map=np.full((9, 12), 37, np.uint8))
     assert np.array_equal(got[0], oracle.filter_plane(y, 37))
