@@ -218,10 +218,17 @@ __device__ __forceinline__ dbk::BlockQp block_qp(const DbkArgs &a, int f, int by
  *   with wave-uniform branches.
  * MODE 0 = filter, MODE 1 = diagnostic copy (same loads/stores, no arithmetic).
  */
-template <bool CHROMA, int MODE, bool NT, bool EDGE, bool QPMAP>
-__device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int bx, bool active)
+template <bool CHROMA, int MODE, bool NT, int PATH, bool QPMAP>
+__device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int bx, bool active, int by0)
 {
-    /* EDGE == false: by is wave-uniform (scalar row offsets); EDGE == true: by and bx may differ per lane */
+    /* PATH 0: interior wave, by == by0 wave-uniform, every lane owns both halves of all 8 rows.
+     * PATH 1: every lane's 8 rows are inside the image, but lanes may sit in different block rows (row-major
+     *         map) and the wave may hold frame-edge blocks (bx == 0 / nbx-1) or idle lanes: still ONE 8-byte
+     *         access per row with a scalar row offset -- the lane's extra rows go into its vector offset, an
+     *         out-of-image half is zeroed after the load (the bytes fetched there belong to the neighbouring
+     *         image row) and is stored by nobody (split store: full lanes 8 bytes, edge lanes 4).
+     * PATH 2: first / last block row: per-lane 4-byte accesses, out-of-image rows and halves via
+     *         out-of-range offsets. */
     const bool lv = active && bx > 0;            /* cols 0..3 inside the image */
     const bool rv = active && bx < a.nbx - 1;    /* cols 4..7 inside the image */
     const int y0 = by * 8 - 4;
@@ -234,12 +241,24 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         a.dst + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
 
     uint32_t L[8], R[8];
-    if constexpr (!EDGE) {
+    if constexpr (PATH == 0) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
             L[r] = w.x;
             R[r] = w.y;
+        }
+    } else if constexpr (PATH == 1) {
+        /* the buffer range check looks at the vector offset alone, so it must not go negative: a bx == 0 lane
+         * (xoff = -4) fetches its 8 bytes one half further right and takes its right half from the first dword */
+        const uint32_t vrow = (uint32_t)((by - by0) * 8) * (uint32_t)a.pitch;
+        const uint32_t voff = active ? (lv ? xoff + vrow : xoff + 4u + vrow) : kOob;
+        const int y0s = by0 * 8 - 4; /* scalar */
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (y0s + r) * (int)a.pitch, aux_bits<NT>());
+            L[r] = lv ? w.x : 0u;
+            R[r] = rv ? (lv ? w.y : w.x) : 0u;
         }
     } else {
         /* straight-line, per-lane offsets: an out-of-image half or row gets an out-of-range offset (load -> 0) */
@@ -254,18 +273,31 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
     }
 
     if constexpr (MODE == 0) {
-        const dbk::BlockBs bs = load_bs_buffer<EDGE>(a, f, by, bx, active);
+        const dbk::BlockBs bs = load_bs_buffer<PATH != 0>(a, f, by, bx, active);
         const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
         dbk::packed_filter_block<CHROMA>(L, R, bs, q, a.diag_ablate);
     }
 
-    if constexpr (!EDGE) {
+    if constexpr (PATH == 0) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             u32x2 w;
             w.x = L[r];
             w.y = R[r];
             __builtin_amdgcn_raw_buffer_store_b64(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
+        }
+    } else if constexpr (PATH == 1) {
+        const uint32_t voff = xoff + (uint32_t)((by - by0) * 8) * (uint32_t)a.pitch;
+        const uint32_t vfull = (lv && rv) ? voff : kOob;                               /* both halves in the image */
+        const uint32_t vhalf = (lv && !rv) ? voff : ((rv && !lv) ? voff + 4u : kOob);  /* exactly one half */
+        const int y0s = by0 * 8 - 4;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            u32x2 w;
+            w.x = L[r];
+            w.y = R[r];
+            __builtin_amdgcn_raw_buffer_store_b64(w, rd, vfull, (y0s + r) * (int)a.pitch, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b32(lv ? L[r] : R[r], rd, vhalf, (y0s + r) * (int)a.pitch, aux_bits<NT>());
         }
     } else {
         const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
@@ -357,6 +389,8 @@ struct WaveCoords {
     int by, bx;     /* offset block of this lane */
     bool active;    /* lane owns a block */
     bool interior;  /* wave-uniform: all 64 lanes in one block row, none touches the frame border */
+    int by0;        /* wave-uniform: block row of the wave's first lane */
+    bool rows_in;   /* wave-uniform: every lane's block row is in 1..nby-2 (all 8 pixel rows inside the image) */
 };
 
 /*
@@ -379,7 +413,9 @@ __device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
         c.bx = blockIdx.z * (int)blockDim.x + (int)threadIdx.x;
         const int wave_bx0 = __builtin_amdgcn_readfirstlane(c.bx) & ~63;
         c.active = c.bx < a.nbx;
-        c.interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && c.by > 0 && c.by < a.nby - 1;
+        c.by0 = c.by;
+        c.rows_in = c.by > 0 && c.by < a.nby - 1;
+        c.interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && c.rows_in;
         return true;
     } else {
         const uint32_t id = blockIdx.x, per_xcd = gridDim.x >> 3;
@@ -391,6 +427,8 @@ __device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
         const uint32_t t0 = wg * blockDim.x + (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u); /* scalar */
         const uint32_t by0 = __umulhi(t0, a.magic_nbx), bx0 = t0 - by0 * (uint32_t)a.nbx;
         c.interior = bx0 >= 1u && bx0 + 63u <= (uint32_t)a.nbx - 2u && by0 >= 1u && by0 + 2u <= (uint32_t)a.nby;
+        c.by0 = (int)by0;
+        c.rows_in = by0 >= 1u && __umulhi(t0 + 63u, a.magic_nbx) + 2u <= (uint32_t)a.nby; /* last lane's row <= nby-2 */
         if (c.interior) {
             c.by = (int)by0;
             c.bx = (int)bx0 + lane;
@@ -429,8 +467,9 @@ __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
 {
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
-    if (c.interior) packed_body<CHROMA, MODE, NT, false, QPMAP>(a, c.by, c.f, c.bx, true);
-    else packed_body<CHROMA, MODE, NT, true, QPMAP>(a, c.by, c.f, c.bx, c.active);
+    if (c.interior) packed_body<CHROMA, MODE, NT, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0);
+    else if (c.rows_in) packed_body<CHROMA, MODE, NT, 1, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0);
+    else packed_body<CHROMA, MODE, NT, 2, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0);
 }
 
 /* ------------------------------------------------------------------------------------------ */
