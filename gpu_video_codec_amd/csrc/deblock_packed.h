@@ -7,8 +7,9 @@
  *     pair A = lines (0,3)  -- the two lines every decision uses, so all decision
  *                              arithmetic runs once, on pair A only
  *     pair B = lines (1,2)
- * Bytes <-> int16 pairs move through v_perm_b32 only (no shifts/masks): 16 perms unpack a segment,
- * 6..16 pack it.  Every intermediate fits int16 (|9*255 + 3*255 + 8| = 3068).
+ * Bytes <-> int16 pairs move through v_perm_b32 only (no shifts/masks); the pairs stay int16 from the
+ * vertical to the horizontal edges (32 unpack + 24 re-pair + 20 pack perms per block).  Every
+ * intermediate fits int16 (|9*255 + 3*255 + 8| = 3068; 16-bit containers up to 11 bit: 12*2047+8).
  *
  * Algebra used (bit-exact with the reference's delta form, cpu.h:1154-1211):
  *   (p2 + 2p1 - 6p0 + 2q0 + q1 + 4) >> 3  ==  ((p2 + 2p1 + 2p0 + 2q0 + q1 + 4) >> 3) - p0
@@ -99,8 +100,6 @@ DBK_HD unsigned lohi_sum(pk a)
     return (uint16_t)(x + (x >> 16));
 }
 DBK_HD pk pk_clamp(pk v, pk lo, pk hi) { return pk_min(pk_max(v, lo), hi); }
-/* exchange the two halves (folds into op_sel of the consuming v_pk op) */
-DBK_HD pk pk_swap(pk a) { return pk{a[1], a[0]}; }
 
 /* v_perm_b32: result byte i = selector byte i picks from {hi:lo}: 0..3 = lo bytes, 4..7 = hi bytes, 0x0c = 0x00 */
 DBK_HD uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
@@ -265,57 +264,6 @@ DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc, int max_v = 255, int 
         normal_pairs(a, b, tc, m5, m6, max_v);
     }
     return true;
-}
-
-/* ---- segments on the register block ----------------------------------------------------------------- */
-
-/* vertical edge on rows R0..R0+3 */
-template <int R0>
-DBK_HD void luma_ver(uint32_t (&L)[8], uint32_t (&R)[8], int beta, int tc)
-{
-    Taps a = unpack_ver(L[R0], L[R0 + 3], R[R0], R[R0 + 3]);
-    Taps b = unpack_ver(L[R0 + 1], L[R0 + 2], R[R0 + 1], R[R0 + 2]);
-    if (!luma_pairs(a, b, beta, tc)) return;
-    /* pack: L row = [p3,p2,p1,p0], R row = [q0,q1,q2,q3] */
-    {
-        const uint32_t t1 = perm(pk_bits(a.p2), pk_bits(a.p3), 0x06020400u);
-        const uint32_t t2 = perm(pk_bits(a.p0), pk_bits(a.p1), 0x06020400u);
-        L[R0] = perm(t2, t1, 0x05040100u);
-        L[R0 + 3] = perm(t2, t1, 0x07060302u);
-        const uint32_t u1 = perm(pk_bits(a.q1), pk_bits(a.q0), 0x06020400u);
-        const uint32_t u2 = perm(pk_bits(a.q3), pk_bits(a.q2), 0x06020400u);
-        R[R0] = perm(u2, u1, 0x05040100u);
-        R[R0 + 3] = perm(u2, u1, 0x07060302u);
-    }
-    {
-        const uint32_t t1 = perm(pk_bits(b.p2), pk_bits(b.p3), 0x06020400u);
-        const uint32_t t2 = perm(pk_bits(b.p0), pk_bits(b.p1), 0x06020400u);
-        L[R0 + 1] = perm(t2, t1, 0x05040100u);
-        L[R0 + 2] = perm(t2, t1, 0x07060302u);
-        const uint32_t u1 = perm(pk_bits(b.q1), pk_bits(b.q0), 0x06020400u);
-        const uint32_t u2 = perm(pk_bits(b.q3), pk_bits(b.q2), 0x06020400u);
-        R[R0 + 1] = perm(u2, u1, 0x05040100u);
-        R[R0 + 2] = perm(u2, u1, 0x07060302u);
-    }
-}
-
-/* horizontal edge between rows 3|4; P taps come from PX (L for hor1, R for hor2 -- the P/Q column
- * mismatch of cpu.h:383-387 vs 411-414), Q taps always from L rows 4..7 */
-DBK_HD void luma_hor(uint32_t (&PX)[8], uint32_t (&L)[8], int beta, int tc)
-{
-    Taps a, b;
-    a.p0 = unpack_hor_a(PX[3]); a.p1 = unpack_hor_a(PX[2]); a.p2 = unpack_hor_a(PX[1]); a.p3 = unpack_hor_a(PX[0]);
-    a.q0 = unpack_hor_a(L[4]);  a.q1 = unpack_hor_a(L[5]);  a.q2 = unpack_hor_a(L[6]);  a.q3 = unpack_hor_a(L[7]);
-    b.p0 = unpack_hor_b(PX[3]); b.p1 = unpack_hor_b(PX[2]); b.p2 = unpack_hor_b(PX[1]); b.p3 = unpack_hor_b(PX[0]);
-    b.q0 = unpack_hor_b(L[4]);  b.q1 = unpack_hor_b(L[5]);  b.q2 = unpack_hor_b(L[6]);  b.q3 = unpack_hor_b(L[7]);
-    if (!luma_pairs(a, b, beta, tc)) return;
-    /* row dword = [A.lo, B.lo, B.hi, A.hi] = columns 0,1,2,3 */
-    PX[3] = perm(pk_bits(b.p0), pk_bits(a.p0), 0x02060400u);
-    PX[2] = perm(pk_bits(b.p1), pk_bits(a.p1), 0x02060400u);
-    PX[1] = perm(pk_bits(b.p2), pk_bits(a.p2), 0x02060400u);
-    L[4] = perm(pk_bits(b.q0), pk_bits(a.q0), 0x02060400u);
-    L[5] = perm(pk_bits(b.q1), pk_bits(a.q1), 0x02060400u);
-    L[6] = perm(pk_bits(b.q2), pk_bits(a.q2), 0x02060400u);
 }
 
 /* ---- chroma (cpu.h:1431-1488): p0/q0 only, no decisions ------------------------------------------- */

@@ -178,14 +178,15 @@ class DeviceBatch:
     This is the layout bench.py times: frame f at base + f*frame_stride, tight pitch."""
 
     def __init__(self, ctx, plane_w, plane_h, n_frames, *, bit_depth=8, sample_bytes=None, is_chroma=False,
-                 in_place=False, per_frame_bs=True):
+                 in_place=False, per_frame_bs=True, pitch=None):
         self.ctx = ctx
         self.w, self.h, self.n = plane_w, plane_h, n_frames
         self.bit_depth = bit_depth
         self.sb = sample_bytes or (1 if bit_depth == 8 else 2)
         self.dtype = np.uint8 if self.sb == 1 else np.uint16
         self.is_chroma = is_chroma
-        self.pitch = plane_w * self.sb
+        self.pitch = plane_w * self.sb if pitch is None else int(pitch)  # bytes; > width*sb leaves row padding
+        assert self.pitch >= plane_w * self.sb and self.pitch % self.sb == 0
         self.frame_bytes = self.pitch * plane_h
         self.src = ctx.alloc(self.frame_bytes * n_frames)
         self.dst = self.src if in_place else ctx.alloc(self.frame_bytes * n_frames)
@@ -201,15 +202,24 @@ class DeviceBatch:
         self.map_stride = 0
         self.ctu_log2 = 6
 
-    def upload_frame(self, f, plane):
-        a = np.ascontiguousarray(plane, self.dtype)
-        assert a.shape == (self.h, self.w)
-        self.src.upload(a, f * self.frame_bytes)
+    def _pitched(self, a, fill=0):
+        """(.., h, w) samples -> (.., h, pitch/sb) with `fill` in the row padding"""
+        ps = self.pitch // self.sb
+        if ps == self.w:
+            return np.ascontiguousarray(a, self.dtype)
+        out = np.full(a.shape[:-1] + (ps,), fill, self.dtype)
+        out[..., : self.w] = a
+        return out
 
-    def upload_all(self, frames):
-        a = np.ascontiguousarray(frames, self.dtype)
+    def upload_frame(self, f, plane, fill=0):
+        a = np.asarray(plane, self.dtype)
+        assert a.shape == (self.h, self.w)
+        self.src.upload(self._pitched(a, fill), f * self.frame_bytes)
+
+    def upload_all(self, frames, fill=0):
+        a = np.asarray(frames, self.dtype)
         assert a.shape == (self.n, self.h, self.w)
-        self.src.upload(a)
+        self.src.upload(self._pitched(a, fill))
 
     def set_bs(self, f, vert, hor):
         assert self.per_frame_bs or f == 0
@@ -235,9 +245,10 @@ class DeviceBatch:
             p.qp_map, p.qp_map_stride, p.ctu_log2 = self.qp_map.ptr, self.map_stride, self.ctu_log2
         return p
 
-    def download_frame(self, f, which="dst"):
+    def download_frame(self, f, which="dst", with_padding=False):
         buf = self.dst if which == "dst" else self.src
-        return buf.download(self.frame_bytes, f * self.frame_bytes, self.dtype).reshape(self.h, self.w)
+        a = buf.download(self.frame_bytes, f * self.frame_bytes, self.dtype).reshape(self.h, self.pitch // self.sb)
+        return a if with_padding else a[:, : self.w]
 
     def free(self):
         for b in (self.src, self.dst, self.vert, self.hor, self.qp_map):

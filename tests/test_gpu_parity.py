@@ -347,3 +347,26 @@ def test_lds_queue_variant_is_bit_exact(ctx, oracle, monkeypatch):
             got = run_batch(ctx, np.stack([y, y[::-1]]), qp, variant=_lib.KERNEL_PACKED)
             assert np.array_equal(got[0], oracle.filter_plane(y, qp)), (name, qp)
             assert np.array_equal(got[1], oracle.filter_plane(y[::-1], qp)), (name, qp)
+
+
+def test_pitched_planes_and_untouched_row_padding(ctx, oracle):
+    """Planes whose pitch exceeds the width (decoder surfaces): same result, and the bytes between the end of a
+    row and the pitch are never written (the last offset block's out-of-image half is not stored)."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    for (w, h, pitch, bd) in [(520, 72, 576, 8), (1032, 40, 1032 + 24, 8), (352, 288, 512, 8), (520, 72, 2 * 520 + 48, 10)]:
+        y = synth.blocky_plane(w, h, seed=w + h, bit_depth=bd)
+        for variant in (_lib.KERNEL_GENERIC, _lib.KERNEL_PACKED):
+            for in_place in (False, True):
+                b = deblock.DeviceBatch(ctx, w, h, 2, bit_depth=bd, pitch=pitch, in_place=in_place)
+                b.upload_all(np.stack([y, y[::-1]]), fill=0xA5 if bd == 8 else 0x3A5)
+                if not in_place:  # pre-fill dst with a pattern so untouched bytes are recognisable
+                    b.dst.upload(np.full(b.frame_bytes * 2, 0x5A, np.uint8))
+                ctx.filter_device(b.planes(), 37, variant=variant)
+                ctx.synchronize()
+                for f, src in enumerate((y, y[::-1])):
+                    full = b.download_frame(f, with_padding=True)
+                    assert np.array_equal(full[:, :w], oracle.filter_plane(src, 37, bit_depth=bd)), (w, pitch, variant, in_place, f)
+                    pad = full[:, w:]
+                    want = (0xA5 if bd == 8 else 0x3A5) if in_place else (0x5A if bd == 8 else 0x5A5A)
+                    assert (pad == want).all(), (w, pitch, variant, in_place, f)
+                b.free()
