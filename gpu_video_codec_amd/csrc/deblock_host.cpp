@@ -52,6 +52,10 @@ struct hevcdbk_context {
     Growable pin[3], dev[3];
     Growable pin_bs, dev_bs, dev_map;
     std::vector<hipEvent_t> timed_events;
+    /* streaming operator: ring of kSeqSlots frames in flight */
+    static constexpr int kSeqSlots = 3;
+    Growable seq_pin[kSeqSlots][3], seq_dev[kSeqSlots][3];
+    hipEvent_t seq_ev[kSeqSlots][3] = {}; /* [slot][0 = h2d done, 1 = kernels done, 2 = d2h done] */
 };
 
 namespace {
@@ -249,6 +253,12 @@ void hevcdbk_destroy(hevcdbk_context *ctx)
     if (ctx->dev_map.p) (void)hipFree(ctx->dev_map.p);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->timed_events) if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < hevcdbk_context::kSeqSlots; k++)
+        for (int i = 0; i < 3; i++) {
+            if (ctx->seq_pin[k][i].p) (void)hipHostFree(ctx->seq_pin[k][i].p);
+            if (ctx->seq_dev[k][i].p) (void)hipFree(ctx->seq_dev[k][i].p);
+            if (ctx->seq_ev[k][i]) (void)hipEventDestroy(ctx->seq_ev[k][i]);
+        }
     if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
     if (ctx->h2d) (void)hipStreamDestroy(ctx->h2d);
     if (ctx->d2h) (void)hipStreamDestroy(ctx->d2h);
@@ -541,6 +551,151 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
         timing->copy_s = copy * 1e-3;
         timing->total_s = timing->exec_s + timing->copy_s; /* gpu.cu:1302 */
         timing->pipelined_s = std::chrono::duration<double>(wall1 - wall0).count();
+    }
+    return HEVCDBK_OK;
+}
+
+/* ---- streaming host operator: H2D(n+1) || kernels(n) || D2H(n-1) ------------------------------------ */
+
+namespace {
+
+/* true when [p, p+bytes) is page-locked host memory the GPU can DMA from directly */
+bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError(); /* ordinary malloc memory: not an error for us */
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+} /* namespace */
+
+extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_frame *frames, unsigned n_frames,
+                                               const hevcdbk_bs *bs, const hevcdbk_qp *qp, const hevcdbk_tables *tables,
+                                               hevcdbk_timing *timing)
+{
+    if (!ctx || !frames || !qp) return HEVCDBK_ERR_ARG;
+    if (n_frames == 0) return HEVCDBK_OK;
+    if (qp->map) return HEVCDBK_ERR_UNSUPPORTED; /* one QP map per frame is not part of the streaming form */
+    const hevcdbk_frame &f0 = frames[0];
+    if (bad_depth(f0.bit_depth, f0.sample_bytes) || !f0.plane[0]) return HEVCDBK_ERR_ARG;
+    const unsigned W = f0.width, H = f0.height, sb = f0.sample_bytes;
+    if (W == 0 || H == 0 || W % 8 != 0 || H % 8 != 0) return HEVCDBK_ERR_DIMENSIONS;
+    const bool chroma = f0.plane[1] && f0.plane[2];
+    if (chroma && ((W / 2) % 8 != 0 || (H / 2) % 8 != 0)) return HEVCDBK_ERR_DIMENSIONS;
+    const int npl = chroma ? 3 : 1;
+    const unsigned pw[3] = {W, W / 2, W / 2}, ph[3] = {H, H / 2, H / 2};
+    for (unsigned i = 0; i < n_frames; i++) {
+        const hevcdbk_frame &fr = frames[i];
+        if (fr.width != W || fr.height != H || fr.bit_depth != f0.bit_depth || fr.sample_bytes != sb) return HEVCDBK_ERR_ARG;
+        for (int k = 0; k < npl; k++)
+            if (!fr.plane[k] || fr.pitch[k] < (size_t)pw[k] * sb) return HEVCDBK_ERR_ARG;
+    }
+    const size_t nv = hevcdbk_num_vert_bs(W, H), nh = hevcdbk_num_hor_bs(W, H);
+    const size_t ncv = chroma ? hevcdbk_num_vert_bs(W / 2, H / 2) : 0, nch = chroma ? hevcdbk_num_hor_bs(W / 2, H / 2) : 0;
+    if (bs) {
+        if ((bs->vert != nullptr) != (bs->hor != nullptr)) return HEVCDBK_ERR_ARG;
+        if (bs->vert && (bs->n_vert != nv || bs->n_hor != nh)) return HEVCDBK_ERR_BS_SIZE;
+        if ((bs->chroma_vert != nullptr) != (bs->chroma_hor != nullptr)) return HEVCDBK_ERR_ARG;
+        if (bs->chroma_vert && (!chroma || bs->n_chroma_vert != ncv || bs->n_chroma_hor != nch)) return HEVCDBK_ERR_BS_SIZE;
+    }
+    if (int rc = bind(ctx)) return rc;
+    constexpr int K = hevcdbk_context::kSeqSlots;
+    size_t row_bytes[3], plane_bytes[3];
+    for (int k = 0; k < npl; k++) {
+        row_bytes[k] = (size_t)pw[k] * sb;
+        plane_bytes[k] = row_bytes[k] * ph[k];
+    }
+    for (int s = 0; s < K; s++) {
+        for (int k = 0; k < npl; k++)
+            if (int rc = grow_device(ctx, ctx->seq_dev[s][k], plane_bytes[k])) return rc;
+        for (int e = 0; e < 3; e++)
+            if (!ctx->seq_ev[s][e]) HIP_TRY(ctx, hipEventCreate(&ctx->seq_ev[s][e]));
+    }
+    /* bS: shared by all frames of the sequence, uploaded once */
+    const size_t bs_bytes = nv + nh + ncv + nch;
+    if (int rc = grow_pinned(ctx, ctx->pin_bs, bs_bytes)) return rc;
+    if (int rc = grow_device(ctx, ctx->dev_bs, bs_bytes)) return rc;
+    uint8_t *hbs = (uint8_t *)ctx->pin_bs.p, *dbs = (uint8_t *)ctx->dev_bs.p;
+    if (bs && bs->vert) { std::memcpy(hbs, bs->vert, nv); std::memcpy(hbs + nv, bs->hor, nh); }
+    else hevcdbk_default_bs(W, H, hbs, hbs + nv);
+    if (chroma) {
+        if (bs && bs->chroma_vert) { std::memcpy(hbs + nv + nh, bs->chroma_vert, ncv); std::memcpy(hbs + nv + nh + ncv, bs->chroma_hor, nch); }
+        else hevcdbk_default_bs(W / 2, H / 2, hbs + nv + nh, hbs + nv + nh + ncv);
+    }
+    const auto wall0 = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipMemcpyAsync(dbs, hbs, bs_bytes, hipMemcpyHostToDevice, ctx->h2d));
+
+    /* un-stage frame `i` (its D2H has been issued into slot i % K) */
+    auto finish = [&](unsigned i) -> int {
+        const int s = (int)(i % K);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->seq_ev[s][2]));
+        hevcdbk_frame &fr = frames[i];
+        for (int k = 0; k < npl; k++) {
+            if (is_pinned_host(fr.plane[k])) continue; /* the DMA wrote the caller's plane directly */
+            for (unsigned r = 0; r < ph[k]; r++)
+                std::memcpy((uint8_t *)fr.plane[k] + r * fr.pitch[k], (const uint8_t *)ctx->seq_pin[s][k].p + r * row_bytes[k], row_bytes[k]);
+        }
+        return HEVCDBK_OK;
+    };
+
+    for (unsigned i = 0; i < n_frames; i++) {
+        const int s = (int)(i % K);
+        if (i >= (unsigned)K)
+            if (int rc = finish(i - K)) return rc; /* slot s is free again once frame i-K has left it */
+        hevcdbk_frame &fr = frames[i];
+        /* H2D: straight from pinned caller memory, or via the slot's pinned staging */
+        for (int k = 0; k < npl; k++) {
+            const void *hsrc = fr.plane[k];
+            size_t hpitch = fr.pitch[k];
+            if (!is_pinned_host(fr.plane[k])) {
+                if (int rc = grow_pinned(ctx, ctx->seq_pin[s][k], plane_bytes[k])) return rc;
+                for (unsigned r = 0; r < ph[k]; r++)
+                    std::memcpy((uint8_t *)ctx->seq_pin[s][k].p + r * row_bytes[k], (const uint8_t *)fr.plane[k] + r * fr.pitch[k], row_bytes[k]);
+                hsrc = ctx->seq_pin[s][k].p;
+                hpitch = row_bytes[k];
+            }
+            HIP_TRY(ctx, hipMemcpy2DAsync(ctx->seq_dev[s][k].p, row_bytes[k], hsrc, hpitch, row_bytes[k], ph[k],
+                                          hipMemcpyHostToDevice, ctx->h2d));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->seq_ev[s][0], ctx->h2d));
+        /* kernels */
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ctx->seq_ev[s][0], 0));
+        for (int k = 0; k < npl; k++) {
+            hevcdbk_device_planes p;
+            std::memset(&p, 0, sizeof(p));
+            p.src = ctx->seq_dev[s][k].p; p.dst = ctx->seq_dev[s][k].p;
+            p.pitch = row_bytes[k]; p.frame_stride = plane_bytes[k]; p.n_frames = 1;
+            p.plane_w = pw[k]; p.plane_h = ph[k]; p.bit_depth = f0.bit_depth; p.sample_bytes = sb;
+            p.is_chroma = k != 0;
+            p.vert_bs = k == 0 ? dbs : dbs + nv + nh;
+            p.hor_bs = k == 0 ? dbs + nv : dbs + nv + nh + ncv;
+            DbkArgs a;
+            if (int rc = planes_to_args(&p, qp->qp, tables, a)) return rc;
+            if (int rc = launch(ctx, a, (int)sb, k != 0, HEVCDBK_KERNEL_AUTO, ctx->compute)) return rc;
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->seq_ev[s][1], ctx->compute));
+        /* D2H */
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ctx->seq_ev[s][1], 0));
+        for (int k = 0; k < npl; k++) {
+            void *hdst = fr.plane[k];
+            size_t hpitch = fr.pitch[k];
+            if (!is_pinned_host(fr.plane[k])) { hdst = ctx->seq_pin[s][k].p; hpitch = row_bytes[k]; }
+            HIP_TRY(ctx, hipMemcpy2DAsync(hdst, hpitch, ctx->seq_dev[s][k].p, row_bytes[k], row_bytes[k], ph[k],
+                                          hipMemcpyDeviceToHost, ctx->d2h));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->seq_ev[s][2], ctx->d2h));
+        /* the H2D of frame i+K must not overwrite this slot before its kernels have read it: the h2d stream waits */
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->seq_ev[s][1], 0));
+    }
+    for (unsigned i = n_frames > (unsigned)K ? n_frames - K : 0; i < n_frames; i++)
+        if (int rc = finish(i)) return rc;
+    const auto wall1 = std::chrono::steady_clock::now();
+    if (timing) {
+        std::memset(timing, 0, sizeof(*timing));
+        timing->pipelined_s = std::chrono::duration<double>(wall1 - wall0).count(); /* whole sequence */
     }
     return HEVCDBK_OK;
 }

@@ -155,6 +155,53 @@ class Context:
         _chk(rc, self.handle)
         return {"exec_s": tm.exec_s, "total_s": tm.total_s, "copy_s": tm.copy_s, "pipelined_s": tm.pipelined_s}
 
+    # -- streaming operator on a sequence of host frames -----------------------------------------
+    def pinned_array(self, shape, dtype=np.uint8):
+        """numpy array in page-locked host memory (hevcdbk_host_malloc_pinned): planes allocated this way are
+        DMA'd in place by filter_sequence / filter_frame, with no staging copy.  Free with free_pinned()."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _chk(_lib.lib().hevcdbk_host_malloc_pinned(self.handle, n, C.byref(p)), self.handle)
+        buf = (C.c_uint8 * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def free_pinned(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            _chk(_lib.lib().hevcdbk_host_free_pinned(self.handle, p), self.handle)
+
+    def filter_sequence(self, frames, *, qp, bit_depth=8, vert_bs=None, hor_bs=None):
+        """frames: list of (y,) or (y, u, v) tuples of writable 2-D numpy planes of one geometry; filtered in
+        place through the 3-deep H2D || kernel || D2H pipeline.  Returns the wall time of the sequence (s)."""
+        arr = (_lib.Frame * len(frames))()
+        for i, pl in enumerate(frames):
+            y = pl[0]
+            arr[i].height, arr[i].width = y.shape
+            arr[i].bit_depth, arr[i].sample_bytes = bit_depth, y.dtype.itemsize
+            for k, p in enumerate(pl):
+                assert p.flags.writeable and p.strides[1] == p.itemsize
+                arr[i].plane[k] = p.ctypes.data
+                arr[i].pitch[k] = p.strides[0]
+        bs = None
+        keep = []
+        if vert_bs is not None:
+            bs = _lib.Bs()
+            for nm, a in (("vert", vert_bs), ("hor", hor_bs)):
+                a = np.ascontiguousarray(a, np.uint8)
+                keep.append(a)
+                setattr(bs, nm, a.ctypes.data)
+                setattr(bs, "n_" + nm, a.size)
+        q = _lib.Qp()
+        q.qp, q.ctu_log2 = int(qp), 6
+        tm = _lib.Timing()
+        rc = _lib.lib().hevc_deblocking_filter_sequence(self.handle, arr, len(frames), None if bs is None else C.byref(bs),
+                                                        C.byref(q), None, C.byref(tm))
+        _chk(rc, self.handle)
+        return tm.pipelined_s
+
     # -- device-resident operator ---------------------------------------------------------------
     def filter_device(self, planes, qp, *, tc_table=None, beta_table=None, variant=KERNEL_AUTO):
         t, _k = _tables(tc_table, beta_table)

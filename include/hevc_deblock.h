@@ -129,6 +129,18 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
                            hevcdbk_timing *timing);
 
 /*
+ * Streaming form for a SEQUENCE of host frames of one geometry (the multi-frame case the reference does
+ * not have).  Three frames are in flight: H2D of frame n+1, the kernels of frame n and
+ * D2H of frame n-1 overlap on the context's three streams.  Planes that already are page-locked
+ * (hevcdbk_host_malloc_pinned, hipHostMalloc, hipHostRegister) are DMA'd in place with no staging copy;
+ * pageable planes go through the context's pinned ring.  bs / tables are shared by all frames;
+ * timing->pipelined_s is the wall time of the whole sequence.  A per-CTU QP map is not accepted here.
+ */
+int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_frame *frames, unsigned n_frames,
+                                    const hevcdbk_bs *bs, const hevcdbk_qp *qp, const hevcdbk_tables *tables,
+                                    hevcdbk_timing *timing);
+
+/*
  * Device-resident form of the same operator, for callers whose planes already live in HBM
  * (the decoder pipeline case, and what bench.py times).  One launch filters n_frames planes of
  * identical geometry.  src and dst are DEVICE pointers and may be equal (in place); blocks are

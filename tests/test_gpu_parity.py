@@ -370,3 +370,39 @@ def test_pitched_planes_and_untouched_row_padding(ctx, oracle):
                     want = (0xA5 if bd == 8 else 0x3A5) if in_place else (0x5A if bd == 8 else 0x5A5A)
                     assert (pad == want).all(), (w, pitch, variant, in_place, f)
                 b.free()
+
+
+def test_streaming_sequence_operator(ctx, oracle, golden_inputs):
+    """hevc_deblocking_filter_sequence: more frames than pipeline slots, pageable and pinned planes mixed,
+    pitched rows, luma-only and Y+U+V; every frame must equal the single-frame result."""
+    from gpu_video_codec_amd import synth
+    # 4:2:0 sequence, pageable memory, 7 frames > 3 slots
+    frames, want = [], []
+    for i in range(7):
+        y, u, v = synth.blocky_yuv420(352, 288, seed=20 + i)
+        want.append(oracle.filter_yuv420(oracle.join_yuv420(y, u, v), 352, 288, 35))
+        frames.append((y.copy(), u.copy(), v.copy()))
+    t = ctx.filter_sequence(frames, qp=35)
+    assert t > 0
+    for i, pl in enumerate(frames):
+        assert oracle.join_yuv420(*pl) == want[i], i
+    # luma-only, pinned (zero-copy) and pageable alternating, with a random luma bS and a padded pitch
+    vb, hb = oracle.lcg_bs(768, 576, 31)
+    src = [np.roll(oracle.split_yuv420(golden_inputs["image2"], 768, 576)[0], 8 * i, axis=1) for i in range(5)]
+    planes, pinned = [], []
+    for i, s in enumerate(src):
+        if i % 2 == 0:
+            buf = ctx.pinned_array((576, 832), np.uint8)
+            pinned.append(buf)
+            buf[:] = 0xEE
+            view = buf[:, :768]
+        else:
+            view = np.full((576, 832), 0xEE, np.uint8)[:, :768]
+        view[:] = s
+        planes.append((view,))
+    ctx.filter_sequence(planes, qp=37, vert_bs=vb, hor_bs=hb)
+    for i, s in enumerate(src):
+        assert np.array_equal(planes[i][0], oracle.filter_plane(s, 37, vert_bs=vb, hor_bs=hb)), i
+        assert (planes[i][0].base[:, 768:] == 0xEE).all() if planes[i][0].base is not None else True
+    for b in pinned:
+        ctx.free_pinned(b)
