@@ -216,6 +216,21 @@ def main():
                 ts.append(time.perf_counter() - a)
             out["e2e_host_frame"] = {"frames_per_s": 1.0 / float(np.median(ts)), "exec_s": tm["exec_s"],
                                      "copy_s": tm["copy_s"], "total_s": tm["total_s"]}
+            # the streaming operator: 3 frames in flight (H2D || kernel || D2H), planes in page-locked memory
+            ns = min(F, 24)
+            pinned = [ctx.pinned_array((h, w), frames.dtype) for _ in range(ns)]
+            for i, p in enumerate(pinned):
+                p[:] = frames[i]
+            ctx.filter_sequence([(p,) for p in pinned[:4]], qp=args.qp, bit_depth=bd)  # warm-up (allocations)
+            for i, p in enumerate(pinned):
+                p[:] = frames[i]
+            t_seq = ctx.filter_sequence([(p,) for p in pinned], qp=args.qp, bit_depth=bd)
+            seq_ok = all(np.array_equal(pinned[i], oracle.filter_plane(frames[i], args.qp, bit_depth=bd)) for i in (0, ns - 1))
+            out["e2e_host_frame"].update({"sequence_frames": ns, "sequence_frames_per_s": ns / t_seq,
+                                          "sequence_pcie_GBps": 2 * w * h * sb * ns / t_seq / 1e9,
+                                          "sequence_bit_exact": bool(seq_ok)})
+            for p in pinned:
+                ctx.free_pinned(p)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[: min(F, 8)], args.qp, bd, args.cpu_budget_s, host_threads())
     batch.free()
