@@ -56,6 +56,10 @@ struct hevcdbk_context {
     static constexpr int kSeqSlots = 3;
     Growable seq_pin[kSeqSlots][3], seq_dev[kSeqSlots][3];
     hipEvent_t seq_ev[kSeqSlots][3] = {}; /* [slot][0 = h2d done, 1 = kernels done, 2 = d2h done] */
+    /* dev_bs holds the DEFAULT bS (cpu.h:92-99) of this geometry when bs_default_at == dev_bs.p: no re-upload */
+    const void *bs_default_at = nullptr;
+    unsigned bs_default_w = 0, bs_default_h = 0;
+    bool bs_default_chroma = false;
 };
 
 namespace {
@@ -182,6 +186,69 @@ int launch(hevcdbk_context *ctx, const DbkArgs &a, int sample_bytes, bool chroma
         return HEVCDBK_ERR_ARG;
     }
     return hip_ok(ctx, e, "kernel launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+}
+
+/*
+ * Put the frame's bS arrays (luma vert | luma hor | chroma vert | chroma hor) into ctx->dev_bs on stream `s`.
+ * Caller-supplied arrays are uploaded every call; the reference's default pattern (cpu.h:92-99) is built and
+ * uploaded once per geometry and stays resident (the reference re-uploads it per call, gpu.cu:1246-1249).
+ */
+int stage_bs(hevcdbk_context *ctx, unsigned W, unsigned H, bool chroma, const hevcdbk_bs *bs, hipStream_t s)
+{
+    const size_t nv = hevcdbk_num_vert_bs(W, H), nh = hevcdbk_num_hor_bs(W, H);
+    const size_t ncv = chroma ? hevcdbk_num_vert_bs(W / 2, H / 2) : 0, nch = chroma ? hevcdbk_num_hor_bs(W / 2, H / 2) : 0;
+    const size_t bs_bytes = nv + nh + ncv + nch;
+    if (int rc = grow_device(ctx, ctx->dev_bs, bs_bytes)) return rc;
+    const bool user = bs && (bs->vert || bs->chroma_vert);
+    if (!user && ctx->bs_default_at == ctx->dev_bs.p && ctx->bs_default_w == W && ctx->bs_default_h == H &&
+        ctx->bs_default_chroma == chroma)
+        return HEVCDBK_OK;
+    /* the pinned copy may still feed an earlier call's upload */
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (int rc = grow_pinned(ctx, ctx->pin_bs, bs_bytes)) return rc;
+    uint8_t *hbs = (uint8_t *)ctx->pin_bs.p;
+    if (bs && bs->vert) { std::memcpy(hbs, bs->vert, nv); std::memcpy(hbs + nv, bs->hor, nh); }
+    else hevcdbk_default_bs(W, H, hbs, hbs + nv);
+    if (chroma) {
+        if (bs && bs->chroma_vert) { std::memcpy(hbs + nv + nh, bs->chroma_vert, ncv); std::memcpy(hbs + nv + nh + ncv, bs->chroma_hor, nch); }
+        else hevcdbk_default_bs(W / 2, H / 2, hbs + nv + nh, hbs + nv + nh + ncv);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dev_bs.p, hbs, bs_bytes, hipMemcpyHostToDevice, s));
+    ctx->bs_default_at = user ? nullptr : ctx->dev_bs.p;
+    ctx->bs_default_w = W; ctx->bs_default_h = H; ctx->bs_default_chroma = chroma;
+    return HEVCDBK_OK;
+}
+
+/* args of plane k of a tightly packed frame whose planes sit at dplane[k] and whose bS sit in ctx->dev_bs */
+int frame_plane_args(hevcdbk_context *ctx, void *const dplane[3], int k, unsigned W, unsigned H, unsigned bit_depth,
+                     unsigned sb, bool chroma, const hevcdbk_qp *qp, const uint8_t *dmap, const hevcdbk_tables *tables,
+                     DbkArgs &a)
+{
+    const size_t nv = hevcdbk_num_vert_bs(W, H), nh = hevcdbk_num_hor_bs(W, H);
+    const size_t ncv = chroma ? hevcdbk_num_vert_bs(W / 2, H / 2) : 0;
+    const uint8_t *dbs = (const uint8_t *)ctx->dev_bs.p;
+    const unsigned pw = k ? W / 2 : W, ph = k ? H / 2 : H;
+    hevcdbk_device_planes p;
+    std::memset(&p, 0, sizeof(p));
+    p.src = dplane[k]; p.dst = dplane[k];
+    p.pitch = (size_t)pw * sb; p.frame_stride = p.pitch * ph; p.n_frames = 1;
+    p.plane_w = pw; p.plane_h = ph; p.bit_depth = bit_depth; p.sample_bytes = sb;
+    p.is_chroma = k != 0;
+    p.vert_bs = k == 0 ? dbs : dbs + nv + nh;
+    p.hor_bs = k == 0 ? dbs + nv : dbs + nv + nh + ncv;
+    p.qp_map = dmap; p.qp_map_stride = qp->map_stride; p.ctu_log2 = qp->ctu_log2;
+    return planes_to_args(&p, qp->qp, tables, a);
+}
+
+/* true (and the launch is done) when the whole frame went out as ONE fused launch */
+int launch_frame_fused(hevcdbk_context *ctx, const DbkArgs *args, int npl, unsigned sb, hipStream_t s, bool *done)
+{
+    const int sbs[3] = {(int)sb, (int)sb, (int)sb};
+    *done = false;
+    if (!dbk_multi_supports(args, npl, sbs)) return HEVCDBK_OK;
+    if (!hip_ok(ctx, dbk_launch_packed_multi(args, npl, s), "kernel launch")) return HEVCDBK_ERR_HIP;
+    *done = true;
+    return HEVCDBK_OK;
 }
 
 } /* namespace */
@@ -440,23 +507,20 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
     }
     if (int rc = bind(ctx)) return rc;
 
-    /* staging buffers (the reference allocates per call, gpu.cu:1103-1169 + 1236-1244; here they persist) */
-    size_t plane_bytes[3];
+    /* staging (the reference allocates per call, gpu.cu:1103-1169 + 1236-1244; here it persists): the planes sit
+     * one after the other, 256-byte aligned, in ONE pinned and ONE device buffer, so a small frame moves in one DMA */
+    size_t plane_bytes[3] = {0, 0, 0}, plane_off[3] = {0, 0, 0}, frame_bytes = 0;
     for (int i = 0; i < npl; i++) {
         plane_bytes[i] = (size_t)pw[i] * ph[i] * sb;
-        if (int rc = grow_pinned(ctx, ctx->pin[i], plane_bytes[i])) return rc;
-        if (int rc = grow_device(ctx, ctx->dev[i], plane_bytes[i])) return rc;
+        plane_off[i] = frame_bytes;
+        frame_bytes = (frame_bytes + plane_bytes[i] + 255) & ~(size_t)255;
     }
-    const size_t bs_bytes = nv + nh + ncv + nch;
-    if (int rc = grow_pinned(ctx, ctx->pin_bs, bs_bytes)) return rc;
-    if (int rc = grow_device(ctx, ctx->dev_bs, bs_bytes)) return rc;
-    uint8_t *hbs = (uint8_t *)ctx->pin_bs.p;
-    uint8_t *dbs = (uint8_t *)ctx->dev_bs.p;
-    if (bs && bs->vert) { std::memcpy(hbs, bs->vert, nv); std::memcpy(hbs + nv, bs->hor, nh); }
-    else hevcdbk_default_bs(W, H, hbs, hbs + nv);
-    if (chroma) {
-        if (bs && bs->chroma_vert) { std::memcpy(hbs + nv + nh, bs->chroma_vert, ncv); std::memcpy(hbs + nv + nh + ncv, bs->chroma_hor, nch); }
-        else hevcdbk_default_bs(W / 2, H / 2, hbs + nv + nh, hbs + nv + nh + ncv);
+    if (int rc = grow_pinned(ctx, ctx->pin[0], frame_bytes)) return rc;
+    if (int rc = grow_device(ctx, ctx->dev[0], frame_bytes)) return rc;
+    uint8_t *hplane[3], *dplane_b[3];
+    for (int i = 0; i < 3; i++) {
+        hplane[i] = (uint8_t *)ctx->pin[0].p + plane_off[i];
+        dplane_b[i] = (uint8_t *)ctx->dev[0].p + plane_off[i];
     }
     const uint8_t *dmap = nullptr;
     size_t map_rows = 0;
@@ -469,73 +533,93 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
     }
 
     const auto wall0 = std::chrono::steady_clock::now();
-    /* pack the caller's (pageable, pitched) planes into the pinned staging buffers */
+    /* pack the caller's (pageable, pitched) planes into the pinned staging buffer */
     for (int i = 0; i < npl; i++) {
         const size_t rb = (size_t)pw[i] * sb;
         for (unsigned r = 0; r < ph[i]; r++)
-            std::memcpy((uint8_t *)ctx->pin[i].p + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
+            std::memcpy(hplane[i] + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
     }
+    DbkArgs args[3];
+    void *dplane[3] = {dplane_b[0], dplane_b[1], dplane_b[2]};
 
     /* events: 0/1 h2d(bs+Y) ; 2/3 h2d(U,V) ; 4/5 kernel Y ; 6/7 kernels U,V ; 8/9 d2h Y ; 10/11 d2h U,V */
     hipEvent_t *ev = ctx->ev;
     HIP_TRY(ctx, hipEventRecord(ev[0], ctx->h2d));
-    HIP_TRY(ctx, hipMemcpyAsync(dbs, hbs, bs_bytes, hipMemcpyHostToDevice, ctx->h2d));
+    if (int rc = stage_bs(ctx, W, H, chroma, bs, ctx->h2d)) return rc;
     if (dmap) HIP_TRY(ctx, hipMemcpyAsync((void *)dmap, qp->map, map_rows * qp->map_stride, hipMemcpyHostToDevice, ctx->h2d));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[0].p, ctx->pin[0].p, plane_bytes[0], hipMemcpyHostToDevice, ctx->h2d));
-    HIP_TRY(ctx, hipEventRecord(ev[1], ctx->h2d));
-    if (chroma) {
-        HIP_TRY(ctx, hipEventRecord(ev[2], ctx->h2d));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[1].p, ctx->pin[1].p, plane_bytes[1], hipMemcpyHostToDevice, ctx->h2d));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[2].p, ctx->pin[2].p, plane_bytes[2], hipMemcpyHostToDevice, ctx->h2d));
-        HIP_TRY(ctx, hipEventRecord(ev[3], ctx->h2d));
-    }
+    HIP_TRY(ctx, hipEventRecord(ev[12], ctx->h2d));
+    for (int i = 0; i < npl; i++)
+        if (int rc = frame_plane_args(ctx, dplane, i, W, H, frame->bit_depth, sb, chroma, qp, dmap, tables, args[i])) return rc;
 
-    /* luma kernel as soon as Y + bS landed; chroma H2D keeps flowing underneath it */
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[1], 0));
-    HIP_TRY(ctx, hipEventRecord(ev[4], ctx->compute));
-    for (int i = 0; i < npl; i++) {
-        if (i == 1) {
-            HIP_TRY(ctx, hipEventRecord(ev[5], ctx->compute));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[3], 0));
-            HIP_TRY(ctx, hipEventRecord(ev[6], ctx->compute));
+    /* Small 8-bit 4:2:0 frames, where a DMA or a launch costs more than the work it carries: one H2D, one fused
+     * launch, one D2H, all on the compute stream (no cross-stream events to pay for). */
+    const int sbs[3] = {(int)sb, (int)sb, (int)sb};
+    const bool small = chroma && frame_bytes <= ((size_t)2 << 20) && dbk_multi_supports(args, npl, sbs);
+    if (small) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[12], 0)); /* the bS upload, if there was one */
+        HIP_TRY(ctx, hipEventRecord(ev[1], ctx->compute));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[0].p, ctx->pin[0].p, frame_bytes, hipMemcpyHostToDevice, ctx->compute));
+        HIP_TRY(ctx, hipEventRecord(ev[4], ctx->compute));
+        bool fused = false;
+        if (int rc = launch_frame_fused(ctx, args, npl, sb, ctx->compute, &fused)) return rc;
+        HIP_TRY(ctx, hipEventRecord(ev[5], ctx->compute));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pin[0].p, ctx->dev[0].p, frame_bytes, hipMemcpyDeviceToHost, ctx->compute));
+        HIP_TRY(ctx, hipEventRecord(ev[9], ctx->compute));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(dplane[0], hplane[0], plane_bytes[0], hipMemcpyHostToDevice, ctx->h2d));
+        HIP_TRY(ctx, hipEventRecord(ev[1], ctx->h2d));
+        if (chroma) {
+            HIP_TRY(ctx, hipEventRecord(ev[2], ctx->h2d));
+            HIP_TRY(ctx, hipMemcpyAsync(dplane[1], hplane[1], plane_off[2] - plane_off[1] + plane_bytes[2], hipMemcpyHostToDevice, ctx->h2d));
+            HIP_TRY(ctx, hipEventRecord(ev[3], ctx->h2d));
         }
-        hevcdbk_device_planes p;
-        std::memset(&p, 0, sizeof(p));
-        p.src = ctx->dev[i].p; p.dst = ctx->dev[i].p;
-        p.pitch = (size_t)pw[i] * sb; p.frame_stride = plane_bytes[i]; p.n_frames = 1;
-        p.plane_w = pw[i]; p.plane_h = ph[i]; p.bit_depth = frame->bit_depth; p.sample_bytes = sb;
-        p.is_chroma = i != 0;
-        p.vert_bs = i == 0 ? dbs : dbs + nv + nh;
-        p.hor_bs = i == 0 ? dbs + nv : dbs + nv + nh + ncv;
-        p.qp_map = dmap; p.qp_map_stride = qp->map_stride; p.ctu_log2 = qp->ctu_log2;
-        DbkArgs a;
-        if (int rc = planes_to_args(&p, qp->qp, tables, a)) return rc;
-        if (int rc = launch(ctx, a, (int)sb, i != 0, HEVCDBK_KERNEL_AUTO, ctx->compute)) return rc;
+        /* luma kernel as soon as Y + bS landed; chroma H2D keeps flowing underneath it */
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[1], 0));
+        HIP_TRY(ctx, hipEventRecord(ev[4], ctx->compute));
+        for (int i = 0; i < npl; i++) {
+            if (i == 1) {
+                HIP_TRY(ctx, hipEventRecord(ev[5], ctx->compute));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[3], 0));
+                HIP_TRY(ctx, hipEventRecord(ev[6], ctx->compute));
+            }
+            if (int rc = launch(ctx, args[i], (int)sb, i != 0, HEVCDBK_KERNEL_AUTO, ctx->compute)) return rc;
+        }
+        HIP_TRY(ctx, hipEventRecord(chroma ? ev[7] : ev[5], ctx->compute));
+        /* D2H of Y overlaps the chroma kernels */
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[5], 0));
+        HIP_TRY(ctx, hipEventRecord(ev[8], ctx->d2h));
+        HIP_TRY(ctx, hipMemcpyAsync(hplane[0], dplane[0], plane_bytes[0], hipMemcpyDeviceToHost, ctx->d2h));
+        HIP_TRY(ctx, hipEventRecord(ev[9], ctx->d2h));
+        if (chroma) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[7], 0));
+            HIP_TRY(ctx, hipEventRecord(ev[10], ctx->d2h));
+            HIP_TRY(ctx, hipMemcpyAsync(hplane[1], dplane[1], plane_off[2] - plane_off[1] + plane_bytes[2], hipMemcpyDeviceToHost, ctx->d2h));
+            HIP_TRY(ctx, hipEventRecord(ev[11], ctx->d2h));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->d2h));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
     }
-    HIP_TRY(ctx, hipEventRecord(chroma ? ev[7] : ev[5], ctx->compute));
-
-    /* D2H of Y overlaps the chroma kernels */
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[5], 0));
-    HIP_TRY(ctx, hipEventRecord(ev[8], ctx->d2h));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin[0].p, ctx->dev[0].p, plane_bytes[0], hipMemcpyDeviceToHost, ctx->d2h));
-    HIP_TRY(ctx, hipEventRecord(ev[9], ctx->d2h));
-    if (chroma) {
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[7], 0));
-        HIP_TRY(ctx, hipEventRecord(ev[10], ctx->d2h));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->pin[1].p, ctx->dev[1].p, plane_bytes[1], hipMemcpyDeviceToHost, ctx->d2h));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->pin[2].p, ctx->dev[2].p, plane_bytes[2], hipMemcpyDeviceToHost, ctx->d2h));
-        HIP_TRY(ctx, hipEventRecord(ev[11], ctx->d2h));
-    }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->d2h));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
 
     for (int i = 0; i < npl; i++) {
         const size_t rb = (size_t)pw[i] * sb;
         for (unsigned r = 0; r < ph[i]; r++)
-            std::memcpy((uint8_t *)frame->plane[i] + r * frame->pitch[i], (const uint8_t *)ctx->pin[i].p + r * rb, rb);
+            std::memcpy((uint8_t *)frame->plane[i] + r * frame->pitch[i], hplane[i] + r * rb, rb);
     }
     const auto wall1 = std::chrono::steady_clock::now();
 
+    if (timing && small) {
+        float ms = 0.f;
+        double copy = 0.0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[1], ev[4])); copy += ms;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[5], ev[9])); copy += ms;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[4], ev[5]));
+        timing->exec_s = ms * 1e-3;
+        timing->copy_s = copy * 1e-3;
+        timing->total_s = timing->exec_s + timing->copy_s; /* gpu.cu:1302 */
+        timing->pipelined_s = std::chrono::duration<double>(wall1 - wall0).count();
+        return HEVCDBK_OK;
+    }
     if (timing) {
         float ms = 0.f;
         double copy = 0.0, exec = 0.0;
@@ -614,19 +698,9 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
         for (int e = 0; e < 3; e++)
             if (!ctx->seq_ev[s][e]) HIP_TRY(ctx, hipEventCreate(&ctx->seq_ev[s][e]));
     }
-    /* bS: shared by all frames of the sequence, uploaded once */
-    const size_t bs_bytes = nv + nh + ncv + nch;
-    if (int rc = grow_pinned(ctx, ctx->pin_bs, bs_bytes)) return rc;
-    if (int rc = grow_device(ctx, ctx->dev_bs, bs_bytes)) return rc;
-    uint8_t *hbs = (uint8_t *)ctx->pin_bs.p, *dbs = (uint8_t *)ctx->dev_bs.p;
-    if (bs && bs->vert) { std::memcpy(hbs, bs->vert, nv); std::memcpy(hbs + nv, bs->hor, nh); }
-    else hevcdbk_default_bs(W, H, hbs, hbs + nv);
-    if (chroma) {
-        if (bs && bs->chroma_vert) { std::memcpy(hbs + nv + nh, bs->chroma_vert, ncv); std::memcpy(hbs + nv + nh + ncv, bs->chroma_hor, nch); }
-        else hevcdbk_default_bs(W / 2, H / 2, hbs + nv + nh, hbs + nv + nh + ncv);
-    }
+    /* bS: shared by all frames of the sequence, uploaded once (the default pattern: once per geometry) */
     const auto wall0 = std::chrono::steady_clock::now();
-    HIP_TRY(ctx, hipMemcpyAsync(dbs, hbs, bs_bytes, hipMemcpyHostToDevice, ctx->h2d));
+    if (int rc = stage_bs(ctx, W, H, chroma, bs, ctx->h2d)) return rc;
 
     /* un-stage frame `i` (its D2H has been issued into slot i % K) */
     auto finish = [&](unsigned i) -> int {
@@ -663,19 +737,16 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
         HIP_TRY(ctx, hipEventRecord(ctx->seq_ev[s][0], ctx->h2d));
         /* kernels */
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ctx->seq_ev[s][0], 0));
-        for (int k = 0; k < npl; k++) {
-            hevcdbk_device_planes p;
-            std::memset(&p, 0, sizeof(p));
-            p.src = ctx->seq_dev[s][k].p; p.dst = ctx->seq_dev[s][k].p;
-            p.pitch = row_bytes[k]; p.frame_stride = plane_bytes[k]; p.n_frames = 1;
-            p.plane_w = pw[k]; p.plane_h = ph[k]; p.bit_depth = f0.bit_depth; p.sample_bytes = sb;
-            p.is_chroma = k != 0;
-            p.vert_bs = k == 0 ? dbs : dbs + nv + nh;
-            p.hor_bs = k == 0 ? dbs + nv : dbs + nv + nh + ncv;
-            DbkArgs a;
-            if (int rc = planes_to_args(&p, qp->qp, tables, a)) return rc;
-            if (int rc = launch(ctx, a, (int)sb, k != 0, HEVCDBK_KERNEL_AUTO, ctx->compute)) return rc;
-        }
+        DbkArgs args[3];
+        void *dplane[3] = {ctx->seq_dev[s][0].p, ctx->seq_dev[s][1].p, ctx->seq_dev[s][2].p};
+        for (int k = 0; k < npl; k++)
+            if (int rc = frame_plane_args(ctx, dplane, k, W, H, f0.bit_depth, sb, chroma, qp, nullptr, tables, args[k])) return rc;
+        bool fused = false;
+        if (chroma)
+            if (int rc = launch_frame_fused(ctx, args, npl, sb, ctx->compute, &fused)) return rc;
+        if (!fused)
+            for (int k = 0; k < npl; k++)
+                if (int rc = launch(ctx, args[k], (int)sb, k != 0, HEVCDBK_KERNEL_AUTO, ctx->compute)) return rc;
         HIP_TRY(ctx, hipEventRecord(ctx->seq_ev[s][1], ctx->compute));
         /* D2H */
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ctx->seq_ev[s][1], 0));
@@ -687,8 +758,8 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
                                           hipMemcpyDeviceToHost, ctx->d2h));
         }
         HIP_TRY(ctx, hipEventRecord(ctx->seq_ev[s][2], ctx->d2h));
-        /* the H2D of frame i+K must not overwrite this slot before its kernels have read it: the h2d stream waits */
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, ctx->seq_ev[s][1], 0));
+        /* slot s is written again by the H2D of frame i+K, which is issued only after finish(i) has seen this
+         * frame's D2H (and so its kernels) complete */
     }
     for (unsigned i = n_frames > (unsigned)K ? n_frames - K : 0; i < n_frames; i++)
         if (int rc = finish(i)) return rc;

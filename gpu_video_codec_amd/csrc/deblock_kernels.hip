@@ -473,6 +473,41 @@ __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* one launch for the planes of a 4:2:0 frame                                */
+/*
+ * The reference launches three kernels per frame (gpu.cu:1269-1285).  For small frames the launches cost more
+ * than the filtering, so the 8-bit scalar-QP planes of a frame go into ONE grid: blockIdx.x runs over the block
+ * rows of Y, then U, then V (row map), a workgroup is as wide as the luma row, and the waves of a chroma row that
+ * lie beyond its width exit at once.
+ */
+template <bool NT>
+__global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiArgs m)
+{
+    const int row = blockIdx.x;
+    const int pl = row >= m.row_end[0] ? (row >= m.row_end[1] ? 2 : 1) : 0; /* scalar */
+    const DbkArgs &a = m.p[pl];
+    WaveCoords c;
+    c.by = row - (pl ? m.row_end[pl - 1] : 0);
+    c.f = blockIdx.y;
+    c.bx = blockIdx.z * (int)blockDim.x + (int)threadIdx.x;
+    const int wave_bx0 = __builtin_amdgcn_readfirstlane(c.bx) & ~63;
+    if (wave_bx0 >= a.nbx) return; /* chroma rows are narrower than the workgroup */
+    c.active = c.bx < a.nbx;
+    c.by0 = c.by;
+    c.rows_in = c.by > 0 && c.by < a.nby - 1;
+    c.interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && c.rows_in;
+    if (pl == 0) {
+        if (c.interior) packed_body<false, 0, NT, 0, false>(a, c.by, c.f, c.bx, true, c.by0);
+        else if (c.rows_in) packed_body<false, 0, NT, 1, false>(a, c.by, c.f, c.bx, c.active, c.by0);
+        else packed_body<false, 0, NT, 2, false>(a, c.by, c.f, c.bx, c.active, c.by0);
+    } else {
+        if (c.interior) packed_body<true, 0, NT, 0, false>(a, c.by, c.f, c.bx, true, c.by0);
+        else if (c.rows_in) packed_body<true, 0, NT, 1, false>(a, c.by, c.f, c.bx, c.active, c.by0);
+        else packed_body<true, 0, NT, 2, false>(a, c.by, c.f, c.bx, c.active, c.by0);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* 8-bit luma with workgroup-level scheduling of the strong filter                              */
 /*
  * Why: strong (cpu.h:1128-1213) and normal (cpu.h:1215-1357) segments are mixed in every wave, so the
@@ -820,5 +855,39 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
     dim3 grid(a.nby, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
     if (tune_nt()) launch_packed_t<true, false>(b, sample_bytes, chroma, mode, grid, block, stream);
     else launch_packed_t<false, false>(b, sample_bytes, chroma, mode, grid, block, stream);
+    return hipGetLastError();
+}
+
+/* all planes 8-bit, scalar QP, same frame count; plane 0 luma, the others chroma */
+bool dbk_multi_supports(const DbkArgs *planes, int n, const int *sample_bytes)
+{
+    static const bool off = [] { const char *e = getenv("HEVCDBK_TUNE"); return e && strstr(e, "nofuse") != nullptr; }();
+    if (off || n < 2 || n > 3) return false;
+    for (int i = 0; i < n; i++)
+        if (sample_bytes[i] != 1 || planes[i].qp_map || planes[i].max_v != 255 || planes[i].n_frames != planes[0].n_frames ||
+            planes[i].nbx > planes[0].nbx)
+            return false;
+    return planes[0].nbx <= 1024;
+}
+
+hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t stream)
+{
+    DbkMultiArgs m;
+    std::memset(&m, 0, sizeof(m));
+    int rows = 0;
+    for (int i = 0; i < 3; i++) {
+        if (i < n) {
+            m.p[i] = planes[i];
+            rows += planes[i].nby;
+        }
+        m.row_end[i] = rows;
+    }
+    if (rows <= 0 || planes[0].n_frames <= 0) return hipSuccess;
+    const int cap = tune_wg_cap();
+    const int per_wg = planes[0].nbx < cap ? planes[0].nbx : cap;
+    dim3 block((per_wg + 63) / 64 * 64, 1, 1);
+    dim3 grid(rows, planes[0].n_frames, (planes[0].nbx + (int)block.x - 1) / (int)block.x);
+    if (tune_nt()) hipLaunchKernelGGL((dbk_packed_multi_kernel<true>), grid, block, 0, stream, m);
+    else hipLaunchKernelGGL((dbk_packed_multi_kernel<false>), grid, block, 0, stream, m);
     return hipGetLastError();
 }

@@ -407,3 +407,53 @@ def test_streaming_sequence_operator(ctx, oracle, golden_inputs):
         assert (fulls[i][:, 768:] == 0xEE).all(), i  # row padding of the caller's planes untouched
     for b in pinned:
         ctx.free_pinned(b)
+
+
+def test_fused_launch_and_resident_default_bs(ctx, oracle):
+    """Small 4:2:0 frames go out as one DMA in, one fused Y+U+V launch, one DMA out, and the default bS stays on
+    the device between calls: alternate geometries, default and caller bS, pitched planes, and the streaming
+    operator, so that every way the resident copy can go stale is exercised."""
+    from gpu_video_codec_amd import synth
+
+    def run(w, h, seed, qp, user_bs, pitched=False):
+        y, u, v = synth.blocky_yuv420(w, h, seed=seed)
+        kw = {}
+        if user_bs:
+            kw["vert_bs"], kw["hor_bs"] = oracle.lcg_bs(w, h, seed)
+            kw["chroma_vert_bs"], kw["chroma_hor_bs"] = oracle.lcg_bs(w // 2, h // 2, seed + 1)
+        want = oracle.join_yuv420(
+            oracle.filter_plane(y, qp, vert_bs=kw.get("vert_bs"), hor_bs=kw.get("hor_bs")),
+            oracle.filter_plane(u, qp, is_chroma=True, vert_bs=kw.get("chroma_vert_bs"), hor_bs=kw.get("chroma_hor_bs")),
+            oracle.filter_plane(v, qp, is_chroma=True, vert_bs=kw.get("chroma_vert_bs"), hor_bs=kw.get("chroma_hor_bs")))
+        if pitched:
+            bufs = [np.full((p.shape[0], p.shape[1] + 24), 0xC3, np.uint8) for p in (y, u, v)]
+            views = [b[:, :p.shape[1]] for b, p in zip(bufs, (y, u, v))]
+            for vw, p in zip(views, (y, u, v)):
+                vw[:] = p
+            ctx.filter_frame(*views, qp=qp, **kw)
+            assert all((b[:, -24:] == 0xC3).all() for b in bufs)
+            got = oracle.join_yuv420(*[np.ascontiguousarray(vw) for vw in views])
+        else:
+            y, u, v = y.copy(), u.copy(), v.copy()
+            ctx.filter_frame(y, u, v, qp=qp, **kw)
+            got = oracle.join_yuv420(y, u, v)
+        assert got == want, (w, h, seed, qp, user_bs, pitched)
+
+    run(352, 288, 1, 35, False)
+    run(352, 288, 2, 30, False)          # resident default bS reused
+    run(352, 288, 3, 41, True)           # caller bS overwrites it
+    run(352, 288, 4, 35, False)          # default must be rebuilt
+    run(288, 352, 5, 35, False)          # same byte count, other geometry
+    run(16, 16, 6, 45, False)            # smallest 4:2:0 frame
+    run(1040, 32, 7, 38, False, True)    # a row wider than one workgroup, pitched planes
+    run(32, 1040, 8, 38, True, True)
+    run(352, 288, 9, 35, False)
+    frames, want = [], []
+    for i in range(4):
+        y, u, v = synth.blocky_yuv420(352, 288, seed=40 + i)
+        want.append(oracle.filter_yuv420(oracle.join_yuv420(y, u, v), 352, 288, 33))
+        frames.append((y.copy(), u.copy(), v.copy()))
+    ctx.filter_sequence(frames, qp=33)
+    for i, pl in enumerate(frames):
+        assert oracle.join_yuv420(*pl) == want[i], i
+    run(352, 288, 10, 35, False)

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Host-frame operator on a small 4:2:0 frame (the reference's own CPU-runnable case, configs[0]): median of the
+reference's timing triple over repeated calls.  HEVCDBK_TUNE=nofuse gives the three-launch form for comparison."""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpu_video_codec_amd import deblock, synth
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=352)
+    ap.add_argument("--height", type=int, default=288)
+    ap.add_argument("--qp", type=int, default=35)
+    ap.add_argument("--reps", type=int, default=200)
+    a = ap.parse_args()
+    ctx = deblock.Context(0)
+    y0, u0, v0 = synth.blocky_yuv420(a.width, a.height, seed=5)
+    rows = []
+    for _ in range(a.reps):
+        y, u, v = y0.copy(), u0.copy(), v0.copy()
+        t0 = time.perf_counter()
+        tm = ctx.filter_frame(y, u, v, qp=a.qp)
+        tm["wall_s"] = time.perf_counter() - t0
+        rows.append(tm)
+    rows = rows[len(rows) // 4:]
+    med = {k: float(np.median([r[k] for r in rows])) for k in rows[0]}
+    med.update(width=a.width, height=a.height, tune=os.environ.get("HEVCDBK_TUNE", ""))
+    print(json.dumps(med))
+
+
+if __name__ == "__main__":
+    main()
