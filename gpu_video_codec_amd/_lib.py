@@ -24,6 +24,7 @@ EXPORTS = [
     "hevcdbk_device_malloc", "hevcdbk_device_free", "hevcdbk_host_malloc_pinned", "hevcdbk_host_free_pinned",
     "hevcdbk_memcpy_h2d", "hevcdbk_memcpy_d2h", "hevcdbk_memcpy_d2d", "hevcdbk_memset_d",
     "hevcdbk_synchronize", "hevcdbk_compute_stream", "hevcdbk_device_run_timed", "hevcdbk_execute_gpu",
+    "hevcdbk_filter_yuv_file",
 ]
 
 
@@ -114,6 +115,8 @@ def lib():
                                                C.POINTER(Tables), C.c_int, C.c_uint, C.POINTER(C.c_float)]
         L.hevcdbk_execute_gpu.argtypes = [C.c_char_p, C.c_char_p, C.c_uint, C.c_uint, C.c_uint,
                                           C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int]
+        L.hevcdbk_filter_yuv_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint, C.c_uint, C.c_uint,
+                                              C.POINTER(Bs), C.POINTER(Tables), C.POINTER(C.c_uint), C.POINTER(Timing)]
         _lib = L
     return _lib
 

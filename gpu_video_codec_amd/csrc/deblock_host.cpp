@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hevc_deblock.h"
@@ -767,6 +768,82 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
     if (timing) {
         std::memset(timing, 0, sizeof(*timing));
         timing->pipelined_s = std::chrono::duration<double>(wall1 - wall0).count(); /* whole sequence */
+    }
+    return HEVCDBK_OK;
+}
+
+/* ---- multi-frame .yuv file -> file: read || filter || write ---------------------------- */
+
+int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *in_name, const char *out_name, unsigned width,
+                            unsigned height, unsigned qp, const hevcdbk_bs *bs, const hevcdbk_tables *tables,
+                            unsigned *n_frames_out, hevcdbk_timing *timing)
+{
+    if (!ctx || !in_name || !out_name || std::strcmp(in_name, out_name) == 0) return HEVCDBK_ERR_ARG;
+    FILE *fi = std::fopen(in_name, "rb");
+    if (!fi) return HEVCDBK_ERR_IO;
+    std::fseek(fi, 0, SEEK_END);
+    const long long length = std::ftell(fi);
+    std::fseek(fi, 0, SEEK_SET);
+    const size_t ysz = (size_t)width * height, csz = ysz / 4, fb = ysz + 2 * csz;
+    /* cpu.h:43-48 order: size first (here: a whole number of frames, at least one), then divisibility */
+    if (fb == 0 || length <= 0 || (unsigned long long)length % fb != 0) { std::fclose(fi); return HEVCDBK_ERR_FILE_SIZE; }
+    if (width % 8 != 0 || height % 8 != 0 || (width / 2) % 8 != 0 || (height / 2) % 8 != 0) {
+        std::fclose(fi);
+        return HEVCDBK_ERR_DIMENSIONS;
+    }
+    const unsigned long long n = (unsigned long long)length / fb;
+    if (n > 0xffffffffull) { std::fclose(fi); return HEVCDBK_ERR_FILE_SIZE; }
+    if (int rc = bind(ctx)) { std::fclose(fi); return rc; }
+    FILE *fo = std::fopen(out_name, "wb");
+    if (!fo) { std::fclose(fi); return HEVCDBK_ERR_IO; }
+
+    /* three pinned chunk buffers: one being read into, one on the GPU, one being written out */
+    size_t chunk = ((size_t)64 << 20) / fb;
+    chunk = chunk < 1 ? 1 : (chunk > 64 ? 64 : chunk);
+    if (chunk > n) chunk = (size_t)n;
+    const size_t nchunks = (size_t)((n + chunk - 1) / chunk);
+    uint8_t *buf[3] = {nullptr, nullptr, nullptr};
+    int rc = HEVCDBK_OK;
+    for (int i = 0; i < 3 && rc == HEVCDBK_OK; i++)
+        if (!hip_ok(ctx, hipHostMalloc((void **)&buf[i], chunk * fb, hipHostMallocDefault), "hipHostMalloc")) rc = HEVCDBK_ERR_HIP;
+    auto frames_in = [&](size_t c) { return (size_t)((c + 1) * chunk <= n ? chunk : n - c * chunk); };
+    const auto wall0 = std::chrono::steady_clock::now();
+    bool io_ok = true;
+    if (rc == HEVCDBK_OK) io_ok = std::fread(buf[0], fb, frames_in(0), fi) == frames_in(0);
+    std::vector<hevcdbk_frame> fr(chunk);
+    const hevcdbk_qp q = {qp, nullptr, 0, 6};
+    for (size_t c = 0; c < nchunks && rc == HEVCDBK_OK && io_ok; c++) {
+        bool rd_ok = true, wr_ok = true;
+        std::thread rd, wr;
+        if (c + 1 < nchunks)
+            rd = std::thread([&, c] { rd_ok = std::fread(buf[(c + 1) % 3], fb, frames_in(c + 1), fi) == frames_in(c + 1); });
+        if (c >= 1)
+            wr = std::thread([&, c] { wr_ok = std::fwrite(buf[(c - 1) % 3], fb, frames_in(c - 1), fo) == frames_in(c - 1); });
+        uint8_t *b = buf[c % 3];
+        const size_t k = frames_in(c);
+        for (size_t i = 0; i < k; i++) {
+            std::memset(&fr[i], 0, sizeof(fr[i]));
+            fr[i].width = width; fr[i].height = height; fr[i].bit_depth = 8; fr[i].sample_bytes = 1;
+            fr[i].plane[0] = b + i * fb; fr[i].plane[1] = b + i * fb + ysz; fr[i].plane[2] = b + i * fb + ysz + csz;
+            fr[i].pitch[0] = width; fr[i].pitch[1] = width / 2; fr[i].pitch[2] = width / 2;
+        }
+        rc = hevc_deblocking_filter_sequence(ctx, fr.data(), (unsigned)k, bs, &q, tables, nullptr);
+        if (rd.joinable()) rd.join();
+        if (wr.joinable()) wr.join();
+        io_ok = rd_ok && wr_ok;
+    }
+    if (rc == HEVCDBK_OK && io_ok)
+        io_ok = std::fwrite(buf[(nchunks - 1) % 3], fb, frames_in(nchunks - 1), fo) == frames_in(nchunks - 1);
+    const auto wall1 = std::chrono::steady_clock::now();
+    std::fclose(fi);
+    if (std::fclose(fo) != 0) io_ok = false;
+    for (auto *b : buf) if (b) (void)hipHostFree(b);
+    if (rc != HEVCDBK_OK) return rc;
+    if (!io_ok) return HEVCDBK_ERR_IO;
+    if (n_frames_out) *n_frames_out = (unsigned)n;
+    if (timing) {
+        std::memset(timing, 0, sizeof(*timing));
+        timing->pipelined_s = std::chrono::duration<double>(wall1 - wall0).count();
     }
     return HEVCDBK_OK;
 }

@@ -2,6 +2,7 @@
  * hevc_deblock_main.cpp -- main.cu-shaped driver (main.cu:109-141) on top of libhevcdbk.so.
  *
  *   hevc_deblock_main [in.yuv out.yuv width height qp [device]]
+ *   hevc_deblock_main --sequence in.yuv out.yuv width height qp [device]     (any number of frames in the file)
  *
  * Without arguments it runs the configuration main.cu ships with (main.cu:128-133:
  * mother-daughter 352x288, QP 35).  Prints the GetGpuDeviceInfo block (main.cu:92-107) and the
@@ -46,6 +47,26 @@ int main(int argc, char **argv)
     std::string out = "mother-daughter_352x288_yv12_filtered_gpu.yuv";
     unsigned width = 352, height = 288, Qp = 35;
     int device = 0;
+    if (argc >= 7 && std::string(argv[1]) == "--sequence") {
+        /* beyond main.cu: a multi-frame file through the streaming pipeline (hevcdbk_filter_yuv_file) */
+        if (argc >= 8) device = std::atoi(argv[7]);
+        hevcdbk_context *ctx = nullptr;
+        int rc = hevcdbk_create(device, &ctx);
+        unsigned n = 0;
+        hevcdbk_timing t;
+        if (rc == HEVCDBK_OK)
+            rc = hevcdbk_filter_yuv_file(ctx, argv[2], argv[3], (unsigned)std::atoi(argv[4]), (unsigned)std::atoi(argv[5]),
+                                         (unsigned)std::atoi(argv[6]), nullptr, nullptr, &n, &t);
+        if (rc != HEVCDBK_OK) {
+            std::fprintf(stderr, "error: %s\n", hevcdbk_strerror(rc));
+            if (ctx) hevcdbk_destroy(ctx);
+            return 1;
+        }
+        std::printf("Frames: %u\nExecution Time with file I/O on GPU: %gs (%g frames/s)\n", n, t.pipelined_s,
+                    t.pipelined_s > 0 ? n / t.pipelined_s : 0.0);
+        hevcdbk_destroy(ctx);
+        return 0;
+    }
     if (argc >= 6) {
         in = argv[1]; out = argv[2];
         width = (unsigned)std::atoi(argv[3]); height = (unsigned)std::atoi(argv[4]); Qp = (unsigned)std::atoi(argv[5]);

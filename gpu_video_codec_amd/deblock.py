@@ -8,6 +8,7 @@ DeblockingFilter / Save) so that tests read like a test of the reference would; 
 DeblockingFilter() runs on the GPU through hevc_deblocking_filter().
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -201,6 +202,29 @@ class Context:
                                                         C.byref(q), None, C.byref(tm))
         _chk(rc, self.handle)
         return tm.pipelined_s
+
+    def filter_yuv_file(self, in_name, out_name, width, height, qp, *, vert_bs=None, hor_bs=None,
+                        tc_table=None, beta_table=None):
+        """Multi-frame planar 8-bit 4:2:0 file -> file (hevcdbk_filter_yuv_file): every frame gets what the
+        reference's ReadYuvFrame -> [SetBoundaryStrenght] -> DeblockingFilter -> Save gives a one-frame file
+        (cpu.h:35-132, 995-1018).  Returns (n_frames, wall seconds including file I/O)."""
+        bs = None
+        keep = []
+        if vert_bs is not None:
+            bs = _lib.Bs()
+            for nm, arr in (("vert", vert_bs), ("hor", hor_bs)):
+                a = np.ascontiguousarray(arr, np.uint8)
+                keep.append(a)
+                setattr(bs, nm, a.ctypes.data)
+                setattr(bs, "n_" + nm, a.size)
+        t, k2 = _tables(tc_table, beta_table)
+        tm = _lib.Timing()
+        n = C.c_uint(0)
+        rc = _lib.lib().hevcdbk_filter_yuv_file(self.handle, os.fsencode(in_name), os.fsencode(out_name), width, height,
+                                                int(qp), None if bs is None else C.byref(bs),
+                                                None if t is None else C.byref(t), C.byref(n), C.byref(tm))
+        _chk(rc, self.handle)
+        return n.value, tm.pipelined_s
 
     # -- device-resident operator ---------------------------------------------------------------
     def filter_device(self, planes, qp, *, tc_table=None, beta_table=None, variant=KERNEL_AUTO):

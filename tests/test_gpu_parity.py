@@ -457,3 +457,71 @@ def test_fused_launch_and_resident_default_bs(ctx, oracle):
     for i, pl in enumerate(frames):
         assert oracle.join_yuv420(*pl) == want[i], i
     run(352, 288, 10, 35, False)
+
+
+def test_multi_frame_yuv_file_operator(ctx, oracle, golden_inputs, tmp_path):
+    """hevcdbk_filter_yuv_file: a sequence file is filtered frame by frame exactly as the reference filters a
+    one-frame file; chunking (more frames than one pinned chunk holds), caller bS, and the error paths."""
+    from gpu_video_codec_amd import synth, _lib
+    # (1) the bundled one-frame file: identical to the reference's own output
+    src = os.path.join(GOLDEN, "mother-daughter_352x288_yv12.yuv")
+    out = tmp_path / "one.yuv"
+    n, wall = ctx.filter_yuv_file(src, str(out), 352, 288, 35)
+    assert n == 1 and wall > 0
+    with open(os.path.join(GOLDEN, "mother-daughter_qp35.ref.yuv"), "rb") as fh:
+        assert out.read_bytes() == fh.read()
+    # (2) 150 CIF frames (> 64 per chunk -> 3 chunks, the last one short), default bS
+    frames = [oracle.join_yuv420(*synth.blocky_yuv420(352, 288, seed=100 + i)) for i in range(150)]
+    seq = tmp_path / "seq.yuv"
+    seq.write_bytes(b"".join(frames))
+    out = tmp_path / "seq_out.yuv"
+    n, _ = ctx.filter_yuv_file(str(seq), str(out), 352, 288, 37)
+    assert n == 150
+    got = out.read_bytes()
+    fb = 352 * 288 * 3 // 2
+    assert len(got) == 150 * fb
+    for i in (0, 1, 63, 64, 65, 127, 128, 149):
+        assert got[i * fb:(i + 1) * fb] == oracle.filter_yuv420(frames[i], 352, 288, 37), i
+    # (3) caller luma bS (SetBoundaryStrenght semantics: chroma keeps the default), 768x576, 5 frames
+    vb, hb = oracle.lcg_bs(768, 576, 77)
+    base = golden_inputs["image2"]
+    fr = [base] + [oracle.join_yuv420(*synth.blocky_yuv420(768, 576, seed=300 + i)) for i in range(4)]
+    seq.write_bytes(b"".join(fr))
+    n, _ = ctx.filter_yuv_file(str(seq), str(out), 768, 576, 30, vert_bs=vb, hor_bs=hb)
+    assert n == 5
+    got = out.read_bytes()
+    fb = 768 * 576 * 3 // 2
+    for i in range(5):
+        assert got[i * fb:(i + 1) * fb] == oracle.filter_yuv420(fr[i], 768, 576, 30, vert_bs=vb, hor_bs=hb), i
+    # (4) errors: ragged size, bad dimensions, same file, missing file
+    rag = tmp_path / "ragged.yuv"
+    rag.write_bytes(frames[0] + b"\0" * 17)
+    for args, code in (((str(rag), str(out), 352, 288, 30), _lib.ERR_FILE_SIZE),
+                       ((str(tmp_path / "missing.yuv"), str(out), 352, 288, 30), _lib.ERR_IO),
+                       ((str(seq), str(seq), 768, 576, 30), _lib.ERR_ARG)):
+        with pytest.raises(_lib.DeblockError) as e:
+            ctx.filter_yuv_file(*args)
+        assert e.value.code == code, args
+    odd = tmp_path / "odd.yuv"
+    odd.write_bytes(b"\0" * (24 * 24 * 3 // 2))  # 24x24: luma fine, chroma 12x12 is not a multiple of 8
+    with pytest.raises(_lib.DeblockError) as e:
+        ctx.filter_yuv_file(str(odd), str(out), 24, 24, 30)
+    assert e.value.code == _lib.ERR_DIMENSIONS
+
+
+def test_reference_padded_plane_layout(ctx, oracle, golden_inputs):
+    """A caller that keeps the reference's (W+8)x(H+8) padded planes (cpu.h:55-82) passes the interior pointer and
+    the padded pitch: no pack/unpack step, the padding stays as it was, the interior equals the reference's Save."""
+    w, h = 352, 288
+    y, u, v = oracle.split_yuv420(golden_inputs["image1"], w, h)
+    padded = []
+    for p in (y, u, v):
+        buf = np.zeros((p.shape[0] + 8, p.shape[1] + 8), np.uint8)
+        buf[4:-4, 4:-4] = p
+        padded.append(buf)
+    views = [b[4:-4, 4:-4] for b in padded]
+    ctx.filter_frame(*views, qp=30)
+    want = oracle.split_yuv420(oracle.filter_yuv420(golden_inputs["image1"], w, h, 30), w, h)
+    for b, vw, wnt in zip(padded, views, want):
+        assert np.array_equal(vw, wnt)
+        assert not b[:4].any() and not b[-4:].any() and not b[:, :4].any() and not b[:, -4:].any()
