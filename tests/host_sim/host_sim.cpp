@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "../../gpu_video_codec_amd/csrc/deblock_core.h"
+#include "../../gpu_video_codec_amd/csrc/deblock_h265.h"
 #if __has_include("../../gpu_video_codec_amd/csrc/deblock_packed.h")
 #define DBK_HOST_SIM 1
 #include "../../gpu_video_codec_amd/csrc/deblock_packed.h"
@@ -112,4 +113,49 @@ extern "C" void host_sim_filter_plane(void *plane, int w, int h, long pitch_byte
         run((uint8_t *)plane, w, h, pitch_bytes, is_chroma, vbs, hbs, tc, beta, max_v, map, map_stride, ctu_log2, tc_tab, beta_tab, shift, packed);
     else
         run((uint16_t *)plane, w, h, pitch_bytes / 2, is_chroma, vbs, hbs, tc, beta, max_v, map, map_stride, ctu_log2, tc_tab, beta_tab, shift, packed);
+}
+
+/* ---- spec-exact mode (deblock_h265.h) ---------------------------------------------------------------- */
+
+template <typename T>
+static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint8_t *vbs4, const uint8_t *hbs4, int qp,
+                     const uint8_t *map, int map_stride, int unit_log2, const dbk::H265Prm &prm)
+{
+    const int nbx = w / 8 + 1, nby = h / 8 + 1, sc = c_idx ? 2 : 1;
+    for (int by = 0; by < nby; by++)
+        for (int bx = 0; bx < nbx; bx++) {
+            int v[8][8], entry[4], qpl[4];
+            load_block(plane, pitch_s, w, h, bx, by, v);
+            dbk::load_block_bs_h265(vbs4, hbs4, bx, by, nbx, nby, w / 8 + 1, w / 4, entry);
+            dbk::h265_block_qpl(map, map_stride, unit_log2, sc, w * sc, h * sc, bx * 8 - 4, by * 8 - 4, qp, qpl);
+            if (c_idx) dbk::filter_block_h265<true>(v, entry, qpl, prm);
+            else dbk::filter_block_h265<false>(v, entry, qpl, prm);
+            store_block(plane, pitch_s, w, h, bx, by, v);
+        }
+}
+
+extern "C" void host_sim_h265_filter_plane(void *plane, int w, int h, long pitch_bytes, int sample_bytes, int bit_depth,
+                                           int c_idx, const uint8_t *vbs4, const uint8_t *hbs4, int qp, const uint8_t *map,
+                                           int map_stride, int unit_log2, int tc_offset_div2, int beta_offset_div2,
+                                           int c_qp_offset)
+{
+    const dbk::H265Prm prm = {tc_offset_div2 * 2, beta_offset_div2 * 2, c_qp_offset, bit_depth - 8, (1 << bit_depth) - 1};
+    if (sample_bytes == 1) run_h265((uint8_t *)plane, w, h, pitch_bytes, c_idx, vbs4, hbs4, qp, map, map_stride, unit_log2, prm);
+    else run_h265((uint16_t *)plane, w, h, pitch_bytes / 2, c_idx, vbs4, hbs4, qp, map, map_stride, unit_log2, prm);
+}
+
+extern "C" void host_sim_h265_derive_bs(const uint16_t *flags, const int16_t *mv0, const int16_t *mv1, const int32_t *ref0,
+                                        const int32_t *ref1, int w, int h, uint8_t *vbs4, uint8_t *hbs4)
+{
+    const dbk::H265Units u = {flags, mv0, mv1, ref0, ref1};
+    const long long uw = w / 4;
+    const int vstride = w / 8 + 1, hstride = w / 4;
+    std::memset(vbs4, 0, (size_t)vstride * (h / 4));
+    std::memset(hbs4, 0, (size_t)(h / 8 + 1) * hstride);
+    for (int y4 = 0; y4 < h / 4; y4++)
+        for (int bx = 1; bx < w / 8; bx++)
+            vbs4[y4 * vstride + bx] = (uint8_t)dbk::h265_bs_of_edge(u, y4 * uw + 2 * bx - 1, y4 * uw + 2 * bx, true);
+    for (int by = 1; by < h / 8; by++)
+        for (int x4 = 0; x4 < w / 4; x4++)
+            hbs4[by * hstride + x4] = (uint8_t)dbk::h265_bs_of_edge(u, (2 * by - 1) * uw + x4, (2 * by) * uw + x4, false);
 }
