@@ -25,6 +25,8 @@ EXPORTS = [
     "hevcdbk_memcpy_h2d", "hevcdbk_memcpy_d2h", "hevcdbk_memcpy_d2d", "hevcdbk_memset_d",
     "hevcdbk_synchronize", "hevcdbk_compute_stream", "hevcdbk_device_run_timed", "hevcdbk_execute_gpu",
     "hevcdbk_filter_yuv_file",
+    "hevcdbk_h265_num_vert_bs", "hevcdbk_h265_num_hor_bs", "hevcdbk_h265_derive_bs_device",
+    "hevc_deblocking_filter_h265_device", "hevc_deblocking_filter_h265",
 ]
 
 
@@ -59,6 +61,19 @@ class DevicePlanes(C.Structure):
                 ("vert_bs_stride", C.c_size_t), ("hor_bs_stride", C.c_size_t),
                 ("qp_map", C.c_void_p), ("qp_map_stride", C.c_uint), ("ctu_log2", C.c_uint),
                 ("qp_map_frame_stride", C.c_size_t)]
+
+
+class H265Params(C.Structure):
+    _fields_ = [("tc_offset_div2", C.c_int), ("beta_offset_div2", C.c_int), ("cb_qp_offset", C.c_int), ("cr_qp_offset", C.c_int)]
+
+
+class H265Units(C.Structure):
+    _fields_ = [("flags", C.c_void_p), ("mv0", C.c_void_p), ("mv1", C.c_void_p), ("ref0", C.c_void_p), ("ref1", C.c_void_p)]
+
+
+H265_BS_MASK, H265_KEEP_P, H265_KEEP_Q = 3, 4, 8
+U_INTRA, U_CBF, U_TU_LEFT, U_TU_TOP, U_PU_LEFT, U_PU_TOP = 1, 2, 4, 8, 16, 32
+U_KEEP, U_DBK_OFF, U_PRED_L0, U_PRED_L1, U_NOX_LEFT, U_NOX_TOP = 64, 128, 256, 512, 1024, 2048
 
 
 class DeviceInfo(C.Structure):
@@ -117,6 +132,16 @@ def lib():
                                           C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int]
         L.hevcdbk_filter_yuv_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint, C.c_uint, C.c_uint,
                                               C.POINTER(Bs), C.POINTER(Tables), C.POINTER(C.c_uint), C.POINTER(Timing)]
+        L.hevcdbk_h265_num_vert_bs.restype = C.c_size_t
+        L.hevcdbk_h265_num_hor_bs.restype = C.c_size_t
+        L.hevcdbk_h265_num_vert_bs.argtypes = [C.c_uint, C.c_uint]
+        L.hevcdbk_h265_num_hor_bs.argtypes = [C.c_uint, C.c_uint]
+        L.hevcdbk_h265_derive_bs_device.argtypes = [C.c_void_p, C.POINTER(H265Units), C.c_uint, C.c_uint, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hevc_deblocking_filter_h265_device.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_int, C.c_uint,
+                                                         C.POINTER(H265Params), C.c_void_p]
+        L.hevc_deblocking_filter_h265.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(H265Units), C.POINTER(Bs),
+                                                  C.POINTER(Qp), C.POINTER(H265Params), C.POINTER(Timing)]
         _lib = L
     return _lib
 

@@ -45,3 +45,18 @@ struct DbkMultiArgs {
 };
 bool dbk_multi_supports(const DbkArgs *planes, int n, const int *sample_bytes);
 hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t stream);
+
+/* ---- spec-exact mode (H.265 clause 8.7.2), deblock_h265.hip ---- */
+struct DbkH265Args {
+    DbkArgs base;    /* geometry, planes, bS arrays (4-sample granular: vstride = plane_w/8+1, hstride = plane_w/4), QP map */
+    int qp;          /* scalar QpY when base.qp_map == NULL */
+    int tc_off;      /* slice_tc_offset_div2 << 1 */
+    int beta_off;    /* slice_beta_offset_div2 << 1 */
+    int c_qp_offset; /* cQpPicOffset of a chroma plane */
+};
+hipError_t dbk_launch_h265(const DbkH265Args &h, int sample_bytes, bool chroma, hipStream_t stream);
+/* 8.7.2.4 on per-4x4-unit arrays in device memory; cvert / chor (4:2:0 chroma arrays) may be NULL */
+hipError_t dbk_launch_h265_bs(const void *flags, const void *mv0, const void *mv1, const void *ref0, const void *ref1, int w,
+                              int h, uint8_t *vert, uint8_t *hor, uint8_t *cvert, uint8_t *chor, hipStream_t stream);
+hipError_t dbk_launch_h265_chroma_bs(const uint8_t *vert, const uint8_t *hor, int w, int h, uint8_t *cvert, uint8_t *chor,
+                                     hipStream_t stream);

@@ -233,6 +233,71 @@ class Context:
                                                       None if t is None else C.byref(t), variant, None)
         _chk(rc, self.handle)
 
+    # -- spec-exact mode (H.265 clause 8.7.2) ------------------------------------------------------
+    def filter_frame_h265(self, y, u=None, v=None, *, qp, bit_depth=8, units=None, vert_bs4=None, hor_bs4=None,
+                          qp_map=None, unit_log2=3, tc_offset_div2=0, beta_offset_div2=0, cb_qp_offset=0, cr_qp_offset=0):
+        """hevc_deblocking_filter_h265 on host planes, in place.  Either `units` = (flags, mv0, mv1, ref0, ref1) per 4x4
+        luma unit (bS derived on the GPU, 8.7.2.4) or the 4-sample-granular luma bS arrays."""
+        fr = _lib.Frame()
+        fr.height, fr.width = y.shape
+        fr.bit_depth, fr.sample_bytes = bit_depth, y.dtype.itemsize
+        for i, p in enumerate([y] + ([u, v] if u is not None else [])):
+            assert p.flags.writeable and p.strides[1] == p.itemsize
+            fr.plane[i] = p.ctypes.data
+            fr.pitch[i] = p.strides[0]
+        keep, un, bs = [], None, None
+        if units is not None:
+            un = _lib.H265Units()
+            for nm, arr, dt in zip(("flags", "mv0", "mv1", "ref0", "ref1"), units, (np.uint16, np.int16, np.int16, np.int32, np.int32)):
+                a = np.ascontiguousarray(arr, dt)
+                keep.append(a)
+                setattr(un, nm, a.ctypes.data)
+        if vert_bs4 is not None:
+            bs = _lib.Bs()
+            for nm, arr in (("vert", vert_bs4), ("hor", hor_bs4)):
+                a = np.ascontiguousarray(arr, np.uint8)
+                keep.append(a)
+                setattr(bs, nm, a.ctypes.data)
+                setattr(bs, "n_" + nm, a.size)
+        q = _lib.Qp()
+        q.qp, q.ctu_log2 = int(qp), unit_log2
+        if qp_map is not None:
+            m = np.ascontiguousarray(qp_map, np.uint8)
+            keep.append(m)
+            q.map, q.map_stride = m.ctypes.data, m.shape[1]
+        prm = _lib.H265Params(tc_offset_div2, beta_offset_div2, cb_qp_offset, cr_qp_offset)
+        tm = _lib.Timing()
+        rc = _lib.lib().hevc_deblocking_filter_h265(self.handle, C.byref(fr), None if un is None else C.byref(un),
+                                                    None if bs is None else C.byref(bs), C.byref(q), C.byref(prm), C.byref(tm))
+        _chk(rc, self.handle)
+        return {"exec_s": tm.exec_s, "total_s": tm.total_s, "copy_s": tm.copy_s, "pipelined_s": tm.pipelined_s}
+
+    def filter_device_h265(self, planes, qp, *, c_idx=0, tc_offset_div2=0, beta_offset_div2=0, cb_qp_offset=0, cr_qp_offset=0):
+        prm = _lib.H265Params(tc_offset_div2, beta_offset_div2, cb_qp_offset, cr_qp_offset)
+        _chk(_lib.lib().hevc_deblocking_filter_h265_device(self.handle, C.byref(planes), c_idx, int(qp), C.byref(prm), None),
+             self.handle)
+
+    def derive_bs_h265(self, units, w, h, *, chroma=True):
+        """8.7.2.4 on the GPU from host arrays; returns (vert, hor[, chroma_vert, chroma_hor]) as host arrays."""
+        arrs = [np.ascontiguousarray(a, dt) for a, dt in zip(units, (np.uint16, np.int16, np.int16, np.int32, np.int32))]
+        bufs = [self.alloc(a.nbytes) for a in arrs]
+        for b, a in zip(bufs, arrs):
+            b.upload(a)
+        L = _lib.lib()
+        sizes = [L.hevcdbk_h265_num_vert_bs(w, h), L.hevcdbk_h265_num_hor_bs(w, h)]
+        if chroma:
+            sizes += [L.hevcdbk_h265_num_vert_bs(w // 2, h // 2), L.hevcdbk_h265_num_hor_bs(w // 2, h // 2)]
+        outs = [self.alloc(max(n, 1)) for n in sizes]
+        un = _lib.H265Units(*[b.ptr for b in bufs])
+        rc = L.hevcdbk_h265_derive_bs_device(self.handle, C.byref(un), w, h, outs[0].ptr, outs[1].ptr,
+                                             outs[2].ptr if chroma else None, outs[3].ptr if chroma else None, None)
+        _chk(rc, self.handle)
+        self.synchronize()
+        res = [o.download(n) for o, n in zip(outs, sizes)]
+        for b in bufs + outs:
+            b.free()
+        return res
+
     def run_timed(self, planes_list, qp, steps, *, variant=KERNEL_AUTO, tc_table=None, beta_table=None):
         """`steps` back-to-back launches of every plane in planes_list; per-step kernel ms (HIP events)."""
         arr = (_lib.DevicePlanes * len(planes_list))(*planes_list)

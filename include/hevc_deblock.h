@@ -214,6 +214,91 @@ int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *input_file_name, c
                             unsigned width, unsigned height, unsigned qp, const hevcdbk_bs *bs,
                             const hevcdbk_tables *tables, unsigned *n_frames, hevcdbk_timing *timing);
 
+/* ==================================================================================================================
+ * Spec-exact mode: ITU-T H.265 (HEVC) clause 8.7.2.
+ *
+ * The reference's filter is HEVC-shaped but not conformant: it hard-codes bS = 2 (cpu.h:91-99) and one QP per frame
+ * (cpu.h:136-137), and its arithmetic differs from the standard in the strong-filter thresholds (cpu.h:1099-1110), the
+ * clip of the normal filter's delta (cpu.h:1256), the chroma formula (cpu.h:1453-1458), the hor2 column pairing
+ * (cpu.h:383-414) and the filtered frame edges.  The entries below are what a decoder needs instead.  They never change
+ * the results of the reference-exact entries above.  Parity: checked against oracle/h265_oracle.c, a restatement of the
+ * standard's text written in picture order (no implementation of the standard exists in the reference or in this
+ * image: "parity unpinned").
+ *
+ * bS arrays are 4-sample granular (the standard's unit):
+ *   vert: (W/8+1) columns x (H/4) rows, entry (y4, bx) = the edge x = 8*bx over rows 4*y4 .. 4*y4+3
+ *   hor:  (H/8+1) rows x (W/4) columns, entry (by, x4) = the edge y = 8*by over columns 4*x4 .. 4*x4+3
+ * for a W x H plane; chroma planes (4:2:0) carry their own arrays in the chroma plane's geometry.  An entry holds the
+ * bS in bits 1:0 and two flags: HEVCDBK_H265_KEEP_P / _KEEP_Q leave the P / Q samples unmodified (pcm_loop_filter_
+ * disabled_flag with a PCM block, cu_transquant_bypass_flag: nDp / nDq = 0 in 8.7.2.5.7).  Edges on the picture boundary
+ * are never filtered, whatever the arrays hold.
+ * ================================================================================================================== */
+#define HEVCDBK_H265_BS_MASK 3u
+#define HEVCDBK_H265_KEEP_P  4u
+#define HEVCDBK_H265_KEEP_Q  8u
+
+typedef struct hevcdbk_h265_params {
+    int tc_offset_div2;   /* slice_tc_offset_div2 (or pps_tc_offset_div2), -6..6 */
+    int beta_offset_div2; /* slice_beta_offset_div2, -6..6 */
+    int cb_qp_offset;     /* pps_cb_qp_offset (+ slice_cb_qp_offset is NOT added: 8.7.2.5.5 uses cQpPicOffset), -12..12 */
+    int cr_qp_offset;     /* pps_cr_qp_offset */
+} hevcdbk_h265_params;
+
+size_t hevcdbk_h265_num_vert_bs(unsigned plane_w, unsigned plane_h); /* (plane_w/8+1) * (plane_h/4) */
+size_t hevcdbk_h265_num_hor_bs(unsigned plane_w, unsigned plane_h);  /* (plane_h/8+1) * (plane_w/4) */
+
+/* per 4x4 luma unit prediction data the bS derivation (8.7.2.4) reads; (W/4) x (H/4) entries, row-major */
+#define HEVCDBK_U_INTRA     0x0001u /* CuPredMode == MODE_INTRA */
+#define HEVCDBK_U_CBF       0x0002u /* the luma transform block covering the unit has non-zero coefficient levels */
+#define HEVCDBK_U_TU_LEFT   0x0004u /* the unit's left border is a transform block edge */
+#define HEVCDBK_U_TU_TOP    0x0008u
+#define HEVCDBK_U_PU_LEFT   0x0010u /* the unit's left border is a prediction block edge */
+#define HEVCDBK_U_PU_TOP    0x0020u
+#define HEVCDBK_U_KEEP      0x0040u /* samples stay unmodified (PCM + pcm_loop_filter_disabled_flag, transquant bypass) */
+#define HEVCDBK_U_DBK_OFF   0x0080u /* slice_deblocking_filter_disabled_flag of the slice holding the unit */
+#define HEVCDBK_U_PRED_L0   0x0100u /* predFlagL0: mv0 / ref0 valid */
+#define HEVCDBK_U_PRED_L1   0x0200u
+#define HEVCDBK_U_NOX_LEFT  0x0400u /* left border is a slice / tile boundary in-loop filtering must not cross */
+#define HEVCDBK_U_NOX_TOP   0x0800u
+
+typedef struct hevcdbk_h265_units {
+    const uint16_t *flags;
+    const int16_t *mv0;   /* [unit][2]: x, y in quarter luma samples */
+    const int16_t *mv1;
+    const int32_t *ref0;  /* identity of the reference PICTURE (e.g. its POC), not its index in the list */
+    const int32_t *ref1;
+} hevcdbk_h265_units;
+
+/*
+ * 8.7.2.4 on the GPU.  `units` and the four outputs are DEVICE pointers; the luma outputs have
+ * hevcdbk_h265_num_vert_bs(w, h) / _hor_bs(w, h) entries, the chroma outputs (4:2:0, may both be NULL) those of the
+ * (w/2) x (h/2) plane: the luma entry at twice the chroma position (8.7.2.5).  Asynchronous on `hip_stream`
+ * (NULL = the context's compute stream).
+ */
+int hevcdbk_h265_derive_bs_device(hevcdbk_context *ctx, const hevcdbk_h265_units *units, unsigned width, unsigned height,
+                                  uint8_t *vert_bs4, uint8_t *hor_bs4, uint8_t *chroma_vert_bs4, uint8_t *chroma_hor_bs4,
+                                  void *hip_stream);
+
+/*
+ * Spec-exact filter on planes that live in HBM.  `planes` as for hevc_deblocking_filter_device, except that vert_bs /
+ * hor_bs are the 4-sample-granular arrays of THIS plane's geometry and qp_map / ctu_log2 describe QpY per unit of
+ * (1 << ctu_log2) luma samples (3 = per 8x8, the finest a quantization group can be).  c_idx 0 = luma, 1 = Cb, 2 = Cr
+ * (selects cb_qp_offset / cr_qp_offset; planes->is_chroma must agree).  The tables are the standard's (Table 8-12, 54 tc
+ * entries); tc index = qPL + 2*(bS-1) + 2*tc_offset_div2, beta index = qPL + 2*beta_offset_div2, chroma through Table 8-10.
+ */
+int hevc_deblocking_filter_h265_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, int c_idx, unsigned qp,
+                                       const hevcdbk_h265_params *params, void *hip_stream);
+
+/*
+ * Host-frame operator of the spec-exact mode: uploads the frame and either `units` (HOST arrays; bS derived on the GPU)
+ * or `bs4` (HOST luma arrays in the 4-sample-granular layout, n_vert / n_hor checked against hevcdbk_h265_num_*; the
+ * chroma arrays are gathered from them on the GPU; its chroma_* members are ignored), filters Y and, when present, Cb and
+ * Cr in place, downloads.  Exactly one of `units` / `bs4` must be non-NULL.  `qp` as for hevc_deblocking_filter.
+ */
+int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_h265_units *units,
+                                const hevcdbk_bs *bs4, const hevcdbk_qp *qp, const hevcdbk_h265_params *params,
+                                hevcdbk_timing *timing);
+
 #ifdef __cplusplus
 }
 #endif

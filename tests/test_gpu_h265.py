@@ -1,0 +1,167 @@
+"""Spec-exact mode (H.265 clause 8.7.2) on the GPU, through the C ABI, against oracle/h265_oracle.c.
+
+PARITY UNPINNED: that oracle restates the standard's text in picture order (all vertical edges, then all horizontal
+edges); the reference implements no conformant filter and no decoder exists in this image (see oracle/h265_oracle.h).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def h265():
+    from oracle import h265 as h
+    return h
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gpu_video_codec_amd import deblock
+    c = deblock.Context(0)
+    yield c
+    c.close()
+
+
+def rand_bs(h265, w, h, rng):
+    vb = (rng.randint(0, 3, h265.num_vert_bs(w, h)) | (rng.randint(0, 8, h265.num_vert_bs(w, h)) == 0) * 4 |
+          (rng.randint(0, 8, h265.num_vert_bs(w, h)) == 0) * 8).astype(np.uint8)
+    hb = (rng.randint(0, 3, h265.num_hor_bs(w, h)) | (rng.randint(0, 8, h265.num_hor_bs(w, h)) == 0) * 4 |
+          (rng.randint(0, 8, h265.num_hor_bs(w, h)) == 0) * 8).astype(np.uint8)
+    return vb, hb
+
+
+def oracle_frame(h265, y, u, v, qp, vb, hb, bit_depth=8, qp_map=None, unit_log2=3, tc=0, beta=0, cb=0, cr=0):
+    h, w = y.shape
+    out = [h265.filter_plane(y, qp, vb, hb, bit_depth=bit_depth, qp_map=qp_map, unit_log2=unit_log2,
+                             tc_offset_div2=tc, beta_offset_div2=beta)]
+    if u is not None:
+        cvb, chb = h265.chroma_bs(vb, hb, w, h)
+        for c_idx, p, off in ((1, u, cb), (2, v, cr)):
+            out.append(h265.filter_plane(p, qp, cvb, chb, c_idx=c_idx, bit_depth=bit_depth, qp_map=qp_map, unit_log2=unit_log2,
+                                         tc_offset_div2=tc, beta_offset_div2=beta, c_qp_offset=off))
+    return out
+
+
+def test_bs_derivation_on_device(ctx, h265):
+    for (w, h, seed) in [(64, 64, 1), (352, 288, 2), (16, 16, 3), (1920, 1088, 4)]:
+        units = h265.random_units(w, h, seed)
+        vb, hb = h265.derive_bs(*units, w, h)
+        cvb, chb = h265.chroma_bs(vb, hb, w, h)
+        gv, gh, gcv, gch = ctx.derive_bs_h265(units, w, h)
+        assert np.array_equal(gv, vb) and np.array_equal(gh, hb), (w, h)
+        assert np.array_equal(gcv, cvb) and np.array_equal(gch, chb), (w, h)
+    gv, gh = ctx.derive_bs_h265(h265.random_units(24, 8, 9), 24, 8, chroma=False)
+    vb, hb = h265.derive_bs(*h265.random_units(24, 8, 9), 24, 8)
+    assert np.array_equal(gv, vb) and np.array_equal(gh, hb)
+
+
+def test_host_frame_operator_from_units(ctx, h265, oracle, golden_inputs):
+    """The whole decoder-side step: prediction data -> bS on the GPU -> Y, Cb, Cr filtered; bundled pictures + synthetic."""
+    from gpu_video_codec_amd import synth
+    rng = np.random.RandomState(3)
+    pics = [("image1", 352, 288), ("mother-daughter", 352, 288), ("image2", 768, 576)]
+    for name, w, h in pics:
+        y, u, v = (p.copy() for p in oracle.split_yuv420(golden_inputs[name], w, h))
+        for qp, offs in ((30, (0, 0, 0, 0)), (37, (2, -1, 3, -4)), (45, (-3, 4, -12, 12))):
+            units = h265.random_units(w, h, seed=qp)
+            vb, hb = h265.derive_bs(*units, w, h)
+            want = oracle_frame(h265, y, u, v, qp, vb, hb, tc=offs[0], beta=offs[1], cb=offs[2], cr=offs[3])
+            gy, gu, gv = y.copy(), u.copy(), v.copy()
+            t = ctx.filter_frame_h265(gy, gu, gv, qp=qp, units=units, tc_offset_div2=offs[0], beta_offset_div2=offs[1],
+                                      cb_qp_offset=offs[2], cr_qp_offset=offs[3])
+            for g, wnt, nm in zip((gy, gu, gv), want, "YUV"):
+                assert np.array_equal(g, wnt), (name, qp, nm)
+            assert t["exec_s"] > 0 and not np.array_equal(gy, y) and not np.array_equal(gu, u)
+    # per-8x8 QP map, 16x16 quantization groups, luma only and 4:2:0
+    w, h = 136 * 2, 72 * 2
+    y, u, v = synth.blocky_yuv420(w, h, seed=8)
+    for unit_log2 in (3, 4, 6):
+        n = 1 << unit_log2
+        qmap = rng.randint(20, 50, ((h + n - 1) // n, (w + n - 1) // n)).astype(np.uint8)
+        vb, hb = rand_bs(h265, w, h, rng)
+        want = oracle_frame(h265, y, u, v, 0, vb, hb, qp_map=qmap, unit_log2=unit_log2, tc=1, cb=-2, cr=5)
+        gy, gu, gv = y.copy(), u.copy(), v.copy()
+        ctx.filter_frame_h265(gy, gu, gv, qp=0, vert_bs4=vb, hor_bs4=hb, qp_map=qmap, unit_log2=unit_log2,
+                              tc_offset_div2=1, cb_qp_offset=-2, cr_qp_offset=5)
+        for g, wnt, nm in zip((gy, gu, gv), want, "YUV"):
+            assert np.array_equal(g, wnt), (unit_log2, nm)
+        gy = y.copy()
+        ctx.filter_frame_h265(gy, qp=0, vert_bs4=vb, hor_bs4=hb, qp_map=qmap, unit_log2=unit_log2, tc_offset_div2=1)
+        assert np.array_equal(gy, want[0])
+
+
+def test_bit_depths_and_edge_sizes(ctx, h265):
+    from gpu_video_codec_amd import synth
+    rng = np.random.RandomState(4)
+    for (w, h, bd) in [(16, 16, 8), (32, 16, 8), (528, 80, 8), (64, 64, 10), (144, 48, 12), (80, 528, 10)]:
+        y, u, v = synth.blocky_yuv420(w, h, seed=w + bd, bit_depth=bd)
+        for qp in (26, 38, 51):
+            vb, hb = rand_bs(h265, w, h, rng)
+            want = oracle_frame(h265, y, u, v, qp, vb, hb, bit_depth=bd, tc=-2, beta=3, cb=1, cr=-1)
+            gy, gu, gv = y.copy(), u.copy(), v.copy()
+            ctx.filter_frame_h265(gy, gu, gv, qp=qp, bit_depth=bd, vert_bs4=vb, hor_bs4=hb, tc_offset_div2=-2,
+                                  beta_offset_div2=3, cb_qp_offset=1, cr_qp_offset=-1)
+            for g, wnt, nm in zip((gy, gu, gv), want, "YUV"):
+                assert np.array_equal(g, wnt), (w, h, bd, qp, nm)
+
+
+def test_device_operator_batch_and_properties(ctx, h265):
+    """hevc_deblocking_filter_h265_device on a batch in HBM (src -> dst and in place), plus properties that hold at any
+    size: bS 0 everywhere is the identity; QP low enough that tc = 0 is the identity; every changed sample lies within 3
+    samples of an 8x8 grid line."""
+    from gpu_video_codec_amd import deblock, synth
+    rng = np.random.RandomState(6)
+    w, h, n = 1920, 1088, 3
+    frames = np.stack([synth.blocky_plane(w, h, seed=50 + i) for i in range(n)])
+    vb, hb = rand_bs(h265, w, h, rng)
+    for in_place in (False, True):
+        b = deblock.DeviceBatch(ctx, w, h, n, in_place=in_place, per_frame_bs=False)
+        b.upload_all(frames)
+        dv, dh = ctx.alloc(vb.size), ctx.alloc(hb.size)
+        dv.upload(vb)
+        dh.upload(hb)
+        p = b.planes()
+        p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
+        ctx.filter_device_h265(p, 35, tc_offset_div2=1)
+        ctx.synchronize()
+        for f in range(n):
+            got = b.download_frame(f)
+            assert np.array_equal(got, h265.filter_plane(frames[f], 35, vb, hb, tc_offset_div2=1)), (in_place, f)
+            ys, xs = np.nonzero(got != frames[f])
+            near = ((xs + 3) % 8) < 6
+            nearh = ((ys + 3) % 8) < 6
+            assert (near | nearh).all()
+        # identity cases
+        b.upload_all(frames)
+        ctx.filter_device_h265(p, 15)  # tc table: Q <= 17 -> 0 (bS 2 adds 2: Q = 17)
+        ctx.synchronize()
+        assert np.array_equal(b.download_frame(1), frames[1])
+        dv.upload(np.zeros_like(vb))
+        dh.upload(np.zeros_like(hb))
+        b.upload_all(frames)
+        ctx.filter_device_h265(p, 40)
+        ctx.synchronize()
+        assert np.array_equal(b.download_frame(2), frames[2])
+        for x in (dv, dh):
+            x.free()
+        b.free()
+
+
+def test_h265_error_codes(ctx, h265):
+    from gpu_video_codec_amd import _lib
+    y = np.zeros((16, 16), np.uint8)
+    vb = np.zeros(h265.num_vert_bs(16, 16), np.uint8)
+    hb = np.zeros(h265.num_hor_bs(16, 16), np.uint8)
+    with pytest.raises(_lib.DeblockError) as e:
+        ctx.filter_frame_h265(y, qp=30)  # neither units nor bS
+    assert e.value.code == _lib.ERR_ARG
+    with pytest.raises(_lib.DeblockError) as e:
+        ctx.filter_frame_h265(y, qp=30, vert_bs4=vb[:-1], hor_bs4=hb)
+    assert e.value.code == _lib.ERR_BS_SIZE
+    with pytest.raises(_lib.DeblockError) as e:
+        ctx.filter_frame_h265(y, qp=30, vert_bs4=vb, hor_bs4=hb, tc_offset_div2=7)
+    assert e.value.code == _lib.ERR_ARG
+    with pytest.raises(_lib.DeblockError) as e:
+        ctx.filter_frame_h265(np.zeros((20, 16), np.uint8), qp=30, vert_bs4=vb, hor_bs4=hb)
+    assert e.value.code == _lib.ERR_DIMENSIONS
