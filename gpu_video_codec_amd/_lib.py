@@ -139,7 +139,7 @@ def lib():
         L.hevcdbk_h265_derive_bs_device.argtypes = [C.c_void_p, C.POINTER(H265Units), C.c_uint, C.c_uint, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hevc_deblocking_filter_h265_device.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_int, C.c_uint,
-                                                         C.POINTER(H265Params), C.c_void_p]
+                                                         C.POINTER(H265Params), C.c_int, C.c_void_p]
         L.hevc_deblocking_filter_h265.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(H265Units), C.POINTER(Bs),
                                                   C.POINTER(Qp), C.POINTER(H265Params), C.POINTER(Timing)]
         _lib = L

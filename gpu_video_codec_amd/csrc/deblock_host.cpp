@@ -815,17 +815,34 @@ int h265_args(const hevcdbk_device_planes *planes, int c_idx, unsigned qp, const
     return HEVCDBK_OK;
 }
 
+int launch_h265(hevcdbk_context *ctx, const DbkH265Args &h, int sample_bytes, bool chroma, int variant, hipStream_t s)
+{
+    const bool can_pack = dbk_packed_h265_supports(h, sample_bytes);
+    hipError_t e;
+    if (variant == HEVCDBK_KERNEL_PACKED) {
+        if (!can_pack) return HEVCDBK_ERR_UNSUPPORTED;
+        e = dbk_launch_packed_h265(h, chroma, s);
+    } else if (variant == HEVCDBK_KERNEL_GENERIC) {
+        e = dbk_launch_h265(h, sample_bytes, chroma, s);
+    } else if (variant == HEVCDBK_KERNEL_AUTO) {
+        e = can_pack ? dbk_launch_packed_h265(h, chroma, s) : dbk_launch_h265(h, sample_bytes, chroma, s);
+    } else {
+        return HEVCDBK_ERR_ARG;
+    }
+    return hip_ok(ctx, e, "kernel launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+}
+
 } /* namespace */
 
 int hevc_deblocking_filter_h265_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, int c_idx, unsigned qp,
-                                       const hevcdbk_h265_params *params, void *hip_stream)
+                                       const hevcdbk_h265_params *params, int kernel_variant, void *hip_stream)
 {
     if (!ctx) return HEVCDBK_ERR_ARG;
     DbkH265Args h;
     if (int rc = h265_args(planes, c_idx, qp, params, h)) return rc;
     if (int rc = bind(ctx)) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
-    return hip_ok(ctx, dbk_launch_h265(h, (int)planes->sample_bytes, c_idx != 0, s), "kernel launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    return launch_h265(ctx, h, (int)planes->sample_bytes, c_idx != 0, kernel_variant, s);
 }
 
 int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_h265_units *units,
@@ -916,7 +933,7 @@ int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, cons
         p.qp_map = dmap; p.qp_map_stride = qp->map_stride; p.ctu_log2 = qp->ctu_log2;
         DbkH265Args h;
         if (int rc = h265_args(&p, i, qp->qp, params, h)) return rc;
-        if (!hip_ok(ctx, dbk_launch_h265(h, (int)sb, i != 0, s), "kernel launch")) return HEVCDBK_ERR_HIP;
+        if (int rc = launch_h265(ctx, h, (int)sb, i != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
     }
     HIP_TRY(ctx, hipEventRecord(ev[2], s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pin[0].p, ctx->dev[0].p, frame_bytes, hipMemcpyDeviceToHost, s));

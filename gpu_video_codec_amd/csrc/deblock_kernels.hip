@@ -18,6 +18,7 @@
 #include "deblock_core.h"
 #include "deblock_kernels.h"
 #include "deblock_packed.h"
+#include "deblock_packed_h265.h"
 
 namespace {
 
@@ -180,6 +181,30 @@ __device__ __forceinline__ dbk::BlockBs load_bs_buffer(const DbkArgs &a, int f, 
     return b;
 }
 
+/* spec-exact mode: the four 4-sample-granular bS bytes of a lane's block (deblock_h265.h load_block_bs_h265); edges on
+ * the picture boundary and halves outside the picture read 0 through an out-of-range offset */
+template <int PATH>
+__device__ __forceinline__ void load_bs_buffer_h265(const DbkArgs &a, int f, int by, int bx, bool active, int (&entry)[4])
+{
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.vert_bs) + (long long)f * a.vert_bs_stride, 0, (uint32_t)a.n_vert, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.hor_bs) + (long long)f * a.hor_bs_stride, 0, (uint32_t)a.n_hor, 0x00020000);
+    if constexpr (PATH == 0) { /* interior wave: by scalar, 1 <= by <= nby-2, 1 <= bx <= nbx-2 */
+        entry[0] = __builtin_amdgcn_raw_buffer_load_b8(rv, (uint32_t)bx, (2 * by - 1) * a.vstride, 0);
+        entry[1] = __builtin_amdgcn_raw_buffer_load_b8(rv, (uint32_t)bx, 2 * by * a.vstride, 0);
+        entry[2] = __builtin_amdgcn_raw_buffer_load_b8(rh, (uint32_t)(2 * bx - 1), by * a.hstride, 0);
+        entry[3] = __builtin_amdgcn_raw_buffer_load_b8(rh, (uint32_t)(2 * bx), by * a.hstride, 0);
+    } else {
+        const bool vedge = active && bx > 0 && bx < a.nbx - 1, hedge = active && by > 0 && by < a.nby - 1;
+        const uint32_t iv = (uint32_t)(2 * by * a.vstride + bx), ih = (uint32_t)(by * a.hstride + 2 * bx);
+        entry[0] = __builtin_amdgcn_raw_buffer_load_b8(rv, (vedge && by > 0) ? iv - (uint32_t)a.vstride : kOob, 0, 0);
+        entry[1] = __builtin_amdgcn_raw_buffer_load_b8(rv, (vedge && by < a.nby - 1) ? iv : kOob, 0, 0);
+        entry[2] = __builtin_amdgcn_raw_buffer_load_b8(rh, (hedge && bx > 0) ? ih - 1u : kOob, 0, 0);
+        entry[3] = __builtin_amdgcn_raw_buffer_load_b8(rh, (hedge && bx < a.nbx - 1) ? ih : kOob, 0, 0);
+    }
+}
+
 /* per-segment tc / beta of a lane's block: the scalar-QP values, or -- QPMAP -- looked up from the per-CTU
  * map exactly as the generic kernel and the oracle do (QP = (QpP + QpQ + 1) >> 1 of the CTUs holding P0 / Q0
  * of the segment's first line) */
@@ -219,7 +244,8 @@ __device__ __forceinline__ dbk::BlockQp block_qp(const DbkArgs &a, int f, int by
  * MODE 0 = filter, MODE 1 = diagnostic copy (same loads/stores, no arithmetic).
  */
 template <bool CHROMA, int MODE, bool NT, int PATH, bool QPMAP>
-__device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int bx, bool active, int by0)
+__device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int bx, bool active, int by0,
+                                            const DbkH265Args *hx = nullptr)
 {
     /* PATH 0: interior wave, by == by0 wave-uniform, every lane owns both halves of all 8 rows.
      * PATH 1: every lane's 8 rows are inside the image, but lanes may sit in different block rows (row-major
@@ -276,6 +302,16 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         const dbk::BlockBs bs = load_bs_buffer<PATH != 0>(a, f, by, bx, active);
         const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
         dbk::packed_filter_block<CHROMA>(L, R, bs, q, a.diag_ablate);
+    } else if constexpr (MODE == 2) { /* spec-exact mode, H.265 8.7.2 */
+        int entry[4], qpl[4];
+        load_bs_buffer_h265<PATH>(a, f, by, bx, active, entry);
+        const int sc = CHROMA ? 2 : 1, bxa = active ? bx : 0;
+        dbk::h265_block_qpl(a.qp_map ? a.qp_map + (long long)f * a.map_frame_stride : nullptr, a.map_stride, a.ctu_log2, sc,
+                            a.plane_w * sc, a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, hx->qp, qpl);
+        const dbk::H265Prm prm = {hx->tc_off, hx->beta_off, hx->c_qp_offset, 0, 255};
+        dbk::H265Seg sg;
+        dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);
+        dbk::packed_filter_block_h265<CHROMA>(L, R, sg);
     }
 
     if constexpr (PATH == 0) {
@@ -470,6 +506,18 @@ __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
     if (c.interior) packed_body<CHROMA, MODE, NT, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0);
     else if (c.rows_in) packed_body<CHROMA, MODE, NT, 1, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0);
     else packed_body<CHROMA, MODE, NT, 2, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0);
+}
+
+/* spec-exact mode (H.265 8.7.2), 8-bit samples, packed-int16 arithmetic: same mapping and memory path */
+template <bool CHROMA, bool LINEAR>
+__global__ __launch_bounds__(1024) void dbk_packed_h265_kernel(const DbkH265Args h)
+{
+    const DbkArgs &a = h.base;
+    WaveCoords c;
+    if (!wave_coords<LINEAR>(a, c)) return;
+    if (c.interior) packed_body<CHROMA, 2, false, 0, false>(a, c.by, c.f, c.bx, true, c.by0, &h);
+    else if (c.rows_in) packed_body<CHROMA, 2, false, 1, false>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
+    else packed_body<CHROMA, 2, false, 2, false>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -814,16 +862,10 @@ static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int
     }
 }
 
-hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, int mode, hipStream_t stream)
+/* work mapping of the packed kernels for plane geometry `a`: fills the row-major numbering fields of `b` and the launch
+ * dimensions; returns true for the row-major (LINEAR) map, false for one workgroup per block row */
+static bool plan_packed(const DbkArgs &a, DbkArgs &b, dim3 &grid, dim3 &block)
 {
-    if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
-    DbkArgs b = a;
-    { const char *e = getenv("HEVCDBK_TUNE"); b.diag_ablate = e && strstr(e, "nostrong") ? 1 : (e && strstr(e, "nonormal") ? 2 : (e && strstr(e, "barriers") ? 4 : 0)); }
-    { const char *e = getenv("HEVCDBK_TUNE"); b.use_queue = (e && strstr(e, "queue")) ? 1 : 0; }
-    if (mode == 1) { /* diagnostic copy only: HEVCDBK_TUNE=align shifts the spans onto their natural alignment */
-        const char *e = getenv("HEVCDBK_TUNE");
-        b.diag_xshift = (e && strstr(e, "align")) ? 4 * sample_bytes : 0;
-    }
     const int cap = tune_wg_cap();
     const long long nb = (long long)a.nbx * a.nby;
     /* row-major block numbering needs exact 32-bit reciprocal division: dividends < 2^32 / divisor */
@@ -841,20 +883,39 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
     if (linear) {
         b.nb_total = (int)nb;
         b.wpf = (int)wpf;
-        { const char *e = getenv("HEVCDBK_TUNE"); b.xcd_swizzle = !(e && strstr(e, "noswz")); }
+        b.xcd_swizzle = !(tune && strstr(tune, "noswz"));
         b.magic_wpf = (uint32_t)((1ull << 32) / (unsigned long long)wpf + 1ull);
         b.magic_nbx = (uint32_t)((1ull << 32) / (unsigned long long)a.nbx + 1ull);
-        dim3 block(wg, 1, 1), grid((unsigned)total, 1, 1);
-        if (tune_nt()) launch_packed_t<true, true>(b, sample_bytes, chroma, mode, grid, block, stream);
-        else launch_packed_t<false, true>(b, sample_bytes, chroma, mode, grid, block, stream);
-        return hipGetLastError();
+        block = dim3(wg, 1, 1);
+        grid = dim3((unsigned)total, 1, 1);
+        return true;
     }
     /* small planes / degenerate divisors: one workgroup per block row, wider rows split into cap-lane chunks */
     const int per_wg = a.nbx < cap ? a.nbx : cap;
-    dim3 block((per_wg + 63) / 64 * 64, 1, 1);
-    dim3 grid(a.nby, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
-    if (tune_nt()) launch_packed_t<true, false>(b, sample_bytes, chroma, mode, grid, block, stream);
-    else launch_packed_t<false, false>(b, sample_bytes, chroma, mode, grid, block, stream);
+    block = dim3((per_wg + 63) / 64 * 64, 1, 1);
+    grid = dim3(a.nby, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
+    return false;
+}
+
+hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, int mode, hipStream_t stream)
+{
+    if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
+    DbkArgs b = a;
+    { const char *e = getenv("HEVCDBK_TUNE"); b.diag_ablate = e && strstr(e, "nostrong") ? 1 : (e && strstr(e, "nonormal") ? 2 : (e && strstr(e, "barriers") ? 4 : 0)); }
+    { const char *e = getenv("HEVCDBK_TUNE"); b.use_queue = (e && strstr(e, "queue")) ? 1 : 0; }
+    if (mode == 1) { /* diagnostic copy only: HEVCDBK_TUNE=align shifts the spans onto their natural alignment */
+        const char *e = getenv("HEVCDBK_TUNE");
+        b.diag_xshift = (e && strstr(e, "align")) ? 4 * sample_bytes : 0;
+    }
+    dim3 grid, block;
+    const bool linear = plan_packed(a, b, grid, block);
+    if (linear) {
+        if (tune_nt()) launch_packed_t<true, true>(b, sample_bytes, chroma, mode, grid, block, stream);
+        else launch_packed_t<false, true>(b, sample_bytes, chroma, mode, grid, block, stream);
+    } else {
+        if (tune_nt()) launch_packed_t<true, false>(b, sample_bytes, chroma, mode, grid, block, stream);
+        else launch_packed_t<false, false>(b, sample_bytes, chroma, mode, grid, block, stream);
+    }
     return hipGetLastError();
 }
 
@@ -889,5 +950,28 @@ hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t str
     dim3 grid(rows, planes[0].n_frames, (planes[0].nbx + (int)block.x - 1) / (int)block.x);
     if (tune_nt()) hipLaunchKernelGGL((dbk_packed_multi_kernel<true>), grid, block, 0, stream, m);
     else hipLaunchKernelGGL((dbk_packed_multi_kernel<false>), grid, block, 0, stream, m);
+    return hipGetLastError();
+}
+
+/* spec-exact mode, packed kernels: 8-bit samples (luma or chroma), scalar QP or QP map */
+bool dbk_packed_h265_supports(const DbkH265Args &h, int sample_bytes)
+{
+    const DbkArgs &a = h.base;
+    return sample_bytes == 1 && a.max_v == 255 && (unsigned long long)a.pitch * (unsigned long long)a.plane_h < (1ull << 31);
+}
+
+hipError_t dbk_launch_packed_h265(const DbkH265Args &h, bool chroma, hipStream_t stream)
+{
+    if (h.base.n_frames <= 0 || h.base.nbx <= 0 || h.base.nby <= 0) return hipSuccess;
+    DbkH265Args g = h;
+    dim3 grid, block;
+    const bool linear = plan_packed(h.base, g.base, grid, block);
+    if (linear) {
+        if (chroma) hipLaunchKernelGGL((dbk_packed_h265_kernel<true, true>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((dbk_packed_h265_kernel<false, true>), grid, block, 0, stream, g);
+    } else {
+        if (chroma) hipLaunchKernelGGL((dbk_packed_h265_kernel<true, false>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((dbk_packed_h265_kernel<false, false>), grid, block, 0, stream, g);
+    }
     return hipGetLastError();
 }

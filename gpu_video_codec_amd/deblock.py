@@ -272,10 +272,11 @@ class Context:
         _chk(rc, self.handle)
         return {"exec_s": tm.exec_s, "total_s": tm.total_s, "copy_s": tm.copy_s, "pipelined_s": tm.pipelined_s}
 
-    def filter_device_h265(self, planes, qp, *, c_idx=0, tc_offset_div2=0, beta_offset_div2=0, cb_qp_offset=0, cr_qp_offset=0):
+    def filter_device_h265(self, planes, qp, *, c_idx=0, tc_offset_div2=0, beta_offset_div2=0, cb_qp_offset=0, cr_qp_offset=0,
+                           variant=KERNEL_AUTO):
         prm = _lib.H265Params(tc_offset_div2, beta_offset_div2, cb_qp_offset, cr_qp_offset)
-        _chk(_lib.lib().hevc_deblocking_filter_h265_device(self.handle, C.byref(planes), c_idx, int(qp), C.byref(prm), None),
-             self.handle)
+        _chk(_lib.lib().hevc_deblocking_filter_h265_device(self.handle, C.byref(planes), c_idx, int(qp), C.byref(prm),
+                                                           variant, None), self.handle)
 
     def derive_bs_h265(self, units, w, h, *, chroma=True):
         """8.7.2.4 on the GPU from host arrays; returns (vert, hor[, chroma_vert, chroma_hor]) as host arrays."""

@@ -285,9 +285,10 @@ int hevcdbk_h265_derive_bs_device(hevcdbk_context *ctx, const hevcdbk_h265_units
  * (1 << ctu_log2) luma samples (3 = per 8x8, the finest a quantization group can be).  c_idx 0 = luma, 1 = Cb, 2 = Cr
  * (selects cb_qp_offset / cr_qp_offset; planes->is_chroma must agree).  The tables are the standard's (Table 8-12, 54 tc
  * entries); tc index = qPL + 2*(bS-1) + 2*tc_offset_div2, beta index = qPL + 2*beta_offset_div2, chroma through Table 8-10.
+ * kernel_variant: HEVCDBK_KERNEL_AUTO, _GENERIC (32-bit arithmetic, every operand kind) or _PACKED (8-bit samples).
  */
 int hevc_deblocking_filter_h265_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, int c_idx, unsigned qp,
-                                       const hevcdbk_h265_params *params, void *hip_stream);
+                                       const hevcdbk_h265_params *params, int kernel_variant, void *hip_stream);
 
 /*
  * Host-frame operator of the spec-exact mode: uploads the frame and either `units` (HOST arrays; bS derived on the GPU)

@@ -13,6 +13,7 @@
 #if __has_include("../../gpu_video_codec_amd/csrc/deblock_packed.h")
 #define DBK_HOST_SIM 1
 #include "../../gpu_video_codec_amd/csrc/deblock_packed.h"
+#include "../../gpu_video_codec_amd/csrc/deblock_packed_h265.h"
 #define HAVE_PACKED 1
 #else
 #define HAVE_PACKED 0
@@ -119,7 +120,7 @@ extern "C" void host_sim_filter_plane(void *plane, int w, int h, long pitch_byte
 
 template <typename T>
 static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint8_t *vbs4, const uint8_t *hbs4, int qp,
-                     const uint8_t *map, int map_stride, int unit_log2, const dbk::H265Prm &prm)
+                     const uint8_t *map, int map_stride, int unit_log2, const dbk::H265Prm &prm, int packed)
 {
     const int nbx = w / 8 + 1, nby = h / 8 + 1, sc = c_idx ? 2 : 1;
     for (int by = 0; by < nby; by++)
@@ -128,6 +129,27 @@ static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint
             load_block(plane, pitch_s, w, h, bx, by, v);
             dbk::load_block_bs_h265(vbs4, hbs4, bx, by, nbx, nby, w / 8 + 1, w / 4, entry);
             dbk::h265_block_qpl(map, map_stride, unit_log2, sc, w * sc, h * sc, bx * 8 - 4, by * 8 - 4, qp, qpl);
+#if HAVE_PACKED
+            if (packed && sizeof(T) == 1) {
+                uint32_t L[8], R[8];
+                for (int r = 0; r < 8; r++) {
+                    L[r] = (uint32_t)v[r][0] | ((uint32_t)v[r][1] << 8) | ((uint32_t)v[r][2] << 16) | ((uint32_t)v[r][3] << 24);
+                    R[r] = (uint32_t)v[r][4] | ((uint32_t)v[r][5] << 8) | ((uint32_t)v[r][6] << 16) | ((uint32_t)v[r][7] << 24);
+                }
+                dbk::H265Seg sg;
+                if (c_idx) { dbk::h265_seg_params<true>(entry, qpl, prm, sg); dbk::packed_filter_block_h265<true>(L, R, sg); }
+                else { dbk::h265_seg_params<false>(entry, qpl, prm, sg); dbk::packed_filter_block_h265<false>(L, R, sg); }
+                for (int r = 0; r < 8; r++)
+                    for (int c = 0; c < 4; c++) {
+                        v[r][c] = (L[r] >> (8 * c)) & 0xff;
+                        v[r][4 + c] = (R[r] >> (8 * c)) & 0xff;
+                    }
+                store_block(plane, pitch_s, w, h, bx, by, v);
+                continue;
+            }
+#else
+            (void)packed;
+#endif
             if (c_idx) dbk::filter_block_h265<true>(v, entry, qpl, prm);
             else dbk::filter_block_h265<false>(v, entry, qpl, prm);
             store_block(plane, pitch_s, w, h, bx, by, v);
@@ -137,11 +159,11 @@ static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint
 extern "C" void host_sim_h265_filter_plane(void *plane, int w, int h, long pitch_bytes, int sample_bytes, int bit_depth,
                                            int c_idx, const uint8_t *vbs4, const uint8_t *hbs4, int qp, const uint8_t *map,
                                            int map_stride, int unit_log2, int tc_offset_div2, int beta_offset_div2,
-                                           int c_qp_offset)
+                                           int c_qp_offset, int packed)
 {
     const dbk::H265Prm prm = {tc_offset_div2 * 2, beta_offset_div2 * 2, c_qp_offset, bit_depth - 8, (1 << bit_depth) - 1};
-    if (sample_bytes == 1) run_h265((uint8_t *)plane, w, h, pitch_bytes, c_idx, vbs4, hbs4, qp, map, map_stride, unit_log2, prm);
-    else run_h265((uint16_t *)plane, w, h, pitch_bytes / 2, c_idx, vbs4, hbs4, qp, map, map_stride, unit_log2, prm);
+    if (sample_bytes == 1) run_h265((uint8_t *)plane, w, h, pitch_bytes, c_idx, vbs4, hbs4, qp, map, map_stride, unit_log2, prm, packed);
+    else run_h265((uint16_t *)plane, w, h, pitch_bytes / 2, c_idx, vbs4, hbs4, qp, map, map_stride, unit_log2, prm, packed);
 }
 
 extern "C" void host_sim_h265_derive_bs(const uint16_t *flags, const int16_t *mv0, const int16_t *mv1, const int32_t *ref0,

@@ -110,12 +110,13 @@ def test_device_operator_batch_and_properties(ctx, h265):
     """hevc_deblocking_filter_h265_device on a batch in HBM (src -> dst and in place), plus properties that hold at any
     size: bS 0 everywhere is the identity; QP low enough that tc = 0 is the identity; every changed sample lies within 3
     samples of an 8x8 grid line."""
-    from gpu_video_codec_amd import deblock, synth
+    from gpu_video_codec_amd import deblock, synth, _lib
     rng = np.random.RandomState(6)
     w, h, n = 1920, 1088, 3
     frames = np.stack([synth.blocky_plane(w, h, seed=50 + i) for i in range(n)])
     vb, hb = rand_bs(h265, w, h, rng)
-    for in_place in (False, True):
+    for in_place, variant in ((False, _lib.KERNEL_PACKED), (True, _lib.KERNEL_PACKED), (False, _lib.KERNEL_GENERIC),
+                              (True, _lib.KERNEL_GENERIC)):
         b = deblock.DeviceBatch(ctx, w, h, n, in_place=in_place, per_frame_bs=False)
         b.upload_all(frames)
         dv, dh = ctx.alloc(vb.size), ctx.alloc(hb.size)
@@ -123,24 +124,24 @@ def test_device_operator_batch_and_properties(ctx, h265):
         dh.upload(hb)
         p = b.planes()
         p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
-        ctx.filter_device_h265(p, 35, tc_offset_div2=1)
+        ctx.filter_device_h265(p, 35, tc_offset_div2=1, variant=variant)
         ctx.synchronize()
         for f in range(n):
             got = b.download_frame(f)
-            assert np.array_equal(got, h265.filter_plane(frames[f], 35, vb, hb, tc_offset_div2=1)), (in_place, f)
+            assert np.array_equal(got, h265.filter_plane(frames[f], 35, vb, hb, tc_offset_div2=1)), (in_place, variant, f)
             ys, xs = np.nonzero(got != frames[f])
             near = ((xs + 3) % 8) < 6
             nearh = ((ys + 3) % 8) < 6
             assert (near | nearh).all()
         # identity cases
         b.upload_all(frames)
-        ctx.filter_device_h265(p, 15)  # tc table: Q <= 17 -> 0 (bS 2 adds 2: Q = 17)
+        ctx.filter_device_h265(p, 15, variant=variant)  # tc table: Q <= 17 -> 0 (bS 2 adds 2: Q = 17)
         ctx.synchronize()
         assert np.array_equal(b.download_frame(1), frames[1])
         dv.upload(np.zeros_like(vb))
         dh.upload(np.zeros_like(hb))
         b.upload_all(frames)
-        ctx.filter_device_h265(p, 40)
+        ctx.filter_device_h265(p, 40, variant=variant)
         ctx.synchronize()
         assert np.array_equal(b.download_frame(2), frames[2])
         for x in (dv, dh):
@@ -165,3 +166,40 @@ def test_h265_error_codes(ctx, h265):
     with pytest.raises(_lib.DeblockError) as e:
         ctx.filter_frame_h265(np.zeros((20, 16), np.uint8), qp=30, vert_bs4=vb, hor_bs4=hb)
     assert e.value.code == _lib.ERR_DIMENSIONS
+
+
+def test_packed_and_generic_kernels_on_awkward_geometries(ctx, h265):
+    """8-bit planes through both spec-mode kernels: widths around the wave / workgroup sizes (partial waves, rows wider
+    than one workgroup -> row-major map), a QP map, chroma with offsets, keep flags, pitched rows."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    rng = np.random.RandomState(12)
+    for (w, h, pitch) in [(8, 8, 8), (520, 24, 576), (1032, 40, 1032), (4104, 16, 4104 + 24), (504, 264, 504)]:
+        for c_idx in (0, 1):
+            y = synth.blocky_plane(w, h, seed=w + c_idx)
+            vb, hb = rand_bs(h265, w, h, rng)
+            sc = 2 if c_idx else 1
+            qmap = rng.randint(24, 48, ((h * sc + 15) // 16, (w * sc + 15) // 16)).astype(np.uint8)
+            for use_map in (False, True):
+                want = h265.filter_plane(y, 36, vb, hb, c_idx=c_idx, qp_map=qmap if use_map else None, unit_log2=4,
+                                         tc_offset_div2=2, beta_offset_div2=-1, c_qp_offset=4 if c_idx else 0)
+                for variant in (_lib.KERNEL_GENERIC, _lib.KERNEL_PACKED):
+                    b = deblock.DeviceBatch(ctx, w, h, 2, is_chroma=bool(c_idx), pitch=pitch, in_place=True, per_frame_bs=False)
+                    b.upload_all(np.stack([y, y]), fill=0x77)
+                    dv, dh, dm = ctx.alloc(vb.size), ctx.alloc(hb.size), ctx.alloc(qmap.size)
+                    dv.upload(vb)
+                    dh.upload(hb)
+                    dm.upload(qmap)
+                    p = b.planes()
+                    p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
+                    if use_map:
+                        p.qp_map, p.qp_map_stride, p.ctu_log2, p.qp_map_frame_stride = dm.ptr, qmap.shape[1], 4, 0
+                    ctx.filter_device_h265(p, 36, c_idx=c_idx, tc_offset_div2=2, beta_offset_div2=-1, cb_qp_offset=4,
+                                           variant=variant)
+                    ctx.synchronize()
+                    for f in range(2):
+                        full = b.download_frame(f, with_padding=True)
+                        assert np.array_equal(full[:, :w], want), (w, h, c_idx, use_map, variant, f)
+                        assert (full[:, w:] == 0x77).all()
+                    for x in (dv, dh, dm):
+                        x.free()
+                    b.free()

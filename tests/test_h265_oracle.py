@@ -48,7 +48,8 @@ def full_bs(h265, w, h, value, rng=None):
     return vb.ravel(), hb.ravel()
 
 
-def sim_filter(sim, plane, qp, vb, hb, *, c_idx=0, bit_depth=8, qp_map=None, unit_log2=3, tc_off=0, beta_off=0, c_qp_off=0):
+def sim_filter(sim, plane, qp, vb, hb, *, c_idx=0, bit_depth=8, qp_map=None, unit_log2=3, tc_off=0, beta_off=0, c_qp_off=0,
+               packed=0):
     out = np.ascontiguousarray(plane).copy()
     h, w = out.shape
     vb = np.ascontiguousarray(vb, np.uint8)
@@ -58,7 +59,7 @@ def sim_filter(sim, plane, qp, vb, hb, *, c_idx=0, bit_depth=8, qp_map=None, uni
         out.ctypes.data_as(C.c_void_p), w, h, C.c_long(out.strides[0]), out.itemsize, bit_depth, c_idx,
         vb.ctypes.data_as(C.c_void_p), hb.ctypes.data_as(C.c_void_p), int(qp),
         None if m is None else m.ctypes.data_as(C.c_void_p), 0 if m is None else m.shape[1], unit_log2,
-        tc_off, beta_off, c_qp_off)
+        tc_off, beta_off, c_qp_off, packed)
     return out
 
 
@@ -243,10 +244,25 @@ def test_kernel_block_arithmetic_equals_picture_order_oracle(h265, sim):
                     want = h265.filter_plane(plane, qp, vb, hb, c_idx=c_idx, bit_depth=bd, qp_map=qmap, unit_log2=3,
                                              tc_offset_div2=offs["tc_off"], beta_offset_div2=offs["beta_off"],
                                              c_qp_offset=offs["c_qp_off"])
-                    got = sim_filter(sim, plane, qp, vb, hb, c_idx=c_idx, bit_depth=bd, qp_map=qmap, unit_log2=3, **offs)
-                    assert np.array_equal(got, want), (w, h, bd, qp, c_idx, use_map, offs)
+                    for packed in ((0, 1) if bd == 8 else (0,)):  # 1 = the packed-int16 form the fast kernels run
+                        got = sim_filter(sim, plane, qp, vb, hb, c_idx=c_idx, bit_depth=bd, qp_map=qmap, unit_log2=3,
+                                         packed=packed, **offs)
+                        assert np.array_equal(got, want), (w, h, bd, qp, c_idx, use_map, offs, packed)
                     cases += (got != plane).any()
     assert cases > 80  # the filter really ran in most cases
+    # samples hugging 0 and 255 with large tc: the conditional Clip1 of the packed form must fire
+    w, h = 64, 32
+    base = np.where(rng.randint(0, 2, (h // 8, w // 8)) == 0, 2, 252)
+    plane = np.clip(np.kron(base, np.ones((8, 8), np.int64)) + rng.randint(-2, 4, (h, w)), 0, 255).astype(np.uint8)
+    plane[:, ::16] = np.clip(plane[:, ::16].astype(int) + 9, 0, 255)
+    for qp in (45, 51):
+        for c_idx in (0, 1):
+            vb, hb = full_bs(h265, w, h, 2)
+            want = h265.filter_plane(plane, qp, vb, hb, c_idx=c_idx, tc_offset_div2=6, beta_offset_div2=6)
+            for packed in (0, 1):
+                got = sim_filter(sim, plane, qp, vb, hb, c_idx=c_idx, tc_off=6, beta_off=6, packed=packed)
+                assert np.array_equal(got, want), (qp, c_idx, packed)
+            assert (want != plane).any()
 
 
 def test_kernel_bs_derivation_equals_oracle(h265, sim):
