@@ -53,6 +53,8 @@ struct DbkH265Args {
     int tc_off;      /* slice_tc_offset_div2 << 1 */
     int beta_off;    /* slice_beta_offset_div2 << 1 */
     int c_qp_offset; /* cQpPicOffset of a chroma plane */
+    /* scalar-QP operands, filled by the launcher: beta, and tc for bS 1 / bS 2 (chroma: bS 2 through QpC) */
+    int beta_s, tc_bs1, tc_bs2;
 };
 hipError_t dbk_launch_h265(const DbkH265Args &h, int sample_bytes, bool chroma, hipStream_t stream); /* 32-bit arithmetic, every operand kind */
 /* packed-int16 arithmetic on the reference-mode kernels' memory path: 8-bit samples */

@@ -245,7 +245,7 @@ __device__ __forceinline__ dbk::BlockQp block_qp(const DbkArgs &a, int f, int by
  */
 template <bool CHROMA, int MODE, bool NT, int PATH, bool QPMAP>
 __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int bx, bool active, int by0,
-                                            const DbkH265Args *hx = nullptr)
+                                            const DbkH265Args *hx = nullptr) /* hx: MODE 2 only */
 {
     /* PATH 0: interior wave, by == by0 wave-uniform, every lane owns both halves of all 8 rows.
      * PATH 1: every lane's 8 rows are inside the image, but lanes may sit in different block rows (row-major
@@ -303,14 +303,24 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
         dbk::packed_filter_block<CHROMA>(L, R, bs, q, a.diag_ablate);
     } else if constexpr (MODE == 2) { /* spec-exact mode, H.265 8.7.2 */
-        int entry[4], qpl[4];
+        int entry[4];
         load_bs_buffer_h265<PATH>(a, f, by, bx, active, entry);
-        const int sc = CHROMA ? 2 : 1, bxa = active ? bx : 0;
-        dbk::h265_block_qpl(a.qp_map ? a.qp_map + (long long)f * a.map_frame_stride : nullptr, a.map_stride, a.ctu_log2, sc,
-                            a.plane_w * sc, a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, hx->qp, qpl);
-        const dbk::H265Prm prm = {hx->tc_off, hx->beta_off, hx->c_qp_offset, 0, 255};
         dbk::H265Seg sg;
-        dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);
+        if constexpr (QPMAP) {
+            int qpl[4];
+            const int sc = CHROMA ? 2 : 1, bxa = active ? bx : 0;
+            dbk::h265_block_qpl(a.qp_map + (long long)f * a.map_frame_stride, a.map_stride, a.ctu_log2, sc, a.plane_w * sc,
+                                a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, hx->qp, qpl);
+            const dbk::H265Prm prm = {hx->tc_off, hx->beta_off, hx->c_qp_offset, 0, 255};
+            dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);
+        } else { /* one QP: beta is a scalar and tc one of two scalars picked by the bS */
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                sg.entry[i] = entry[i];
+                sg.beta[i] = hx->beta_s;
+                sg.tc[i] = (entry[i] & dbk::kH265BsMask) == 2 ? hx->tc_bs2 : hx->tc_bs1;
+            }
+        }
         dbk::packed_filter_block_h265<CHROMA>(L, R, sg);
     }
 
@@ -509,17 +519,21 @@ __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
 }
 
 /* spec-exact mode (H.265 8.7.2), 8-bit samples, packed-int16 arithmetic: same mapping and memory path */
-template <bool CHROMA, bool LINEAR>
-__global__ __launch_bounds__(1024) void dbk_packed_h265_kernel(const DbkH265Args h)
+template <bool CHROMA, bool LINEAR, bool QPMAP>
+__device__ __forceinline__ void packed_h265_dispatch(const DbkH265Args &h)
 {
     const DbkArgs &a = h.base;
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
-    if (c.interior) packed_body<CHROMA, 2, false, 0, false>(a, c.by, c.f, c.bx, true, c.by0, &h);
-    else if (c.rows_in) packed_body<CHROMA, 2, false, 1, false>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
-    else packed_body<CHROMA, 2, false, 2, false>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
+    if (c.interior) packed_body<CHROMA, 2, false, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0, &h);
+    else if (c.rows_in) packed_body<CHROMA, 2, false, 1, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
+    else packed_body<CHROMA, 2, false, 2, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
 }
-
+template <bool CHROMA, bool LINEAR, bool QPMAP>
+__global__ __launch_bounds__(1024) void dbk_packed_h265_kernel(const DbkH265Args h)
+{
+    packed_h265_dispatch<CHROMA, LINEAR, QPMAP>(h);
+}
 /* ------------------------------------------------------------------------------------------ */
 /* one launch for the planes of a 4:2:0 frame                                */
 /*
@@ -966,12 +980,30 @@ hipError_t dbk_launch_packed_h265(const DbkH265Args &h, bool chroma, hipStream_t
     DbkH265Args g = h;
     dim3 grid, block;
     const bool linear = plan_packed(h.base, g.base, grid, block);
-    if (linear) {
-        if (chroma) hipLaunchKernelGGL((dbk_packed_h265_kernel<true, true>), grid, block, 0, stream, g);
-        else hipLaunchKernelGGL((dbk_packed_h265_kernel<false, true>), grid, block, 0, stream, g);
-    } else {
-        if (chroma) hipLaunchKernelGGL((dbk_packed_h265_kernel<true, false>), grid, block, 0, stream, g);
-        else hipLaunchKernelGGL((dbk_packed_h265_kernel<false, false>), grid, block, 0, stream, g);
+    {
+        const int qp = h.qp;
+        auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        g.beta_s = dbk::h265_beta(cl(qp + h.beta_off, 0, 51));
+        if (chroma) {
+            g.tc_bs1 = 0;
+            g.tc_bs2 = dbk::h265_tc(cl(dbk::h265_chroma_qp(qp + h.c_qp_offset) + 2 + h.tc_off, 0, 53));
+        } else {
+            g.tc_bs1 = dbk::h265_tc(cl(qp + h.tc_off, 0, 53));
+            g.tc_bs2 = dbk::h265_tc(cl(qp + 2 + h.tc_off, 0, 53));
+        }
     }
+#define DBK_H265_LAUNCH(C, LIN)                                                                                     \
+    do {                                                                                                            \
+        if (g.base.qp_map) hipLaunchKernelGGL((dbk_packed_h265_kernel<C, LIN, true>), grid, block, 0, stream, g);   \
+        else hipLaunchKernelGGL((dbk_packed_h265_kernel<C, LIN, false>), grid, block, 0, stream, g);                \
+    } while (0)
+    if (linear) {
+        if (chroma) DBK_H265_LAUNCH(true, true);
+        else DBK_H265_LAUNCH(false, true);
+    } else {
+        if (chroma) DBK_H265_LAUNCH(true, false);
+        else DBK_H265_LAUNCH(false, false);
+    }
+#undef DBK_H265_LAUNCH
     return hipGetLastError();
 }
