@@ -525,3 +525,33 @@ def test_reference_padded_plane_layout(ctx, oracle, golden_inputs):
     for b, vw, wnt in zip(padded, views, want):
         assert np.array_equal(vw, wnt)
         assert not b[:4].any() and not b[-4:].any() and not b[:, :4].any() and not b[:, -4:].any()
+
+
+def test_two_contexts_driven_from_two_host_threads(oracle):
+    """a context is single-threaded, different contexts may run concurrently (the reference's GPU
+    path is process-global state, gpu.cu:37-77).  Two threads, each with its own context, filter different frames with
+    different QPs at the same time; both must get their own exact results, repeatedly."""
+    import threading
+    from gpu_video_codec_amd import deblock, synth
+    errors = []
+
+    def work(seed, qp, w, h):
+        try:
+            ctx = deblock.Context(0)
+            for it in range(12):
+                y, u, v = synth.blocky_yuv420(w, h, seed=seed + it)
+                want = oracle.filter_yuv420(oracle.join_yuv420(y, u, v), w, h, qp)
+                y, u, v = y.copy(), u.copy(), v.copy()
+                ctx.filter_frame(y, u, v, qp=qp)
+                if oracle.join_yuv420(y, u, v) != want:
+                    errors.append((seed, it))
+            ctx.close()
+        except Exception as e:  # noqa
+            errors.append((seed, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(100, 30, 352, 288)), threading.Thread(target=work, args=(200, 41, 768, 576))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
