@@ -26,7 +26,7 @@ EXPORTS = [
     "hevcdbk_synchronize", "hevcdbk_compute_stream", "hevcdbk_device_run_timed", "hevcdbk_execute_gpu",
     "hevcdbk_filter_yuv_file",
     "hevcdbk_h265_num_vert_bs", "hevcdbk_h265_num_hor_bs", "hevcdbk_h265_derive_bs_device",
-    "hevc_deblocking_filter_h265_device", "hevc_deblocking_filter_h265",
+    "hevc_deblocking_filter_h265_device", "hevc_deblocking_filter_h265", "hevc_sao_filter_device",
 ]
 
 
@@ -74,6 +74,9 @@ class H265Units(C.Structure):
 H265_BS_MASK, H265_KEEP_P, H265_KEEP_Q = 3, 4, 8
 U_INTRA, U_CBF, U_TU_LEFT, U_TU_TOP, U_PU_LEFT, U_PU_TOP = 1, 2, 4, 8, 16, 32
 U_KEEP, U_DBK_OFF, U_PRED_L0, U_PRED_L1, U_NOX_LEFT, U_NOX_TOP = 64, 128, 256, 512, 1024, 2048
+
+
+SAO_CTB_DTYPE = [("type", "u1"), ("cls", "u1"), ("offset", "i1", (4,))]  # numpy dtype of hevcdbk_sao_ctb
 
 
 class DeviceInfo(C.Structure):
@@ -142,6 +145,8 @@ def lib():
                                                          C.POINTER(H265Params), C.c_int, C.c_void_p]
         L.hevc_deblocking_filter_h265.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(H265Units), C.POINTER(Bs),
                                                   C.POINTER(Qp), C.POINTER(H265Params), C.POINTER(Timing)]
+        L.hevc_sao_filter_device.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_void_p, C.c_uint, C.c_size_t, C.c_uint,
+                                             C.c_void_p, C.c_uint, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 

@@ -958,6 +958,39 @@ int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, cons
     return HEVCDBK_OK;
 }
 
+/* ---- sample adaptive offset (H.265 clause 8.7.3) ------------------------------------------------------------- */
+
+static_assert(sizeof(hevcdbk_sao_ctb) == sizeof(DbkSaoCtb) && sizeof(DbkSaoCtb) == 6, "SAO CTB entry layout");
+
+int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p, const hevcdbk_sao_ctb *params,
+                           unsigned params_stride, size_t params_frame_stride, unsigned ctb_log2, const uint8_t *keep,
+                           unsigned keep_stride, size_t keep_frame_stride, void *hip_stream)
+{
+    if (!ctx || !p || !p->src || !p->dst || p->src == p->dst || !params) return HEVCDBK_ERR_ARG;
+    if (bad_depth(p->bit_depth, p->sample_bytes)) return HEVCDBK_ERR_ARG;
+    if (p->plane_w == 0 || p->plane_h == 0 || p->plane_w % 8 != 0 || p->plane_h % 8 != 0) return HEVCDBK_ERR_DIMENSIONS;
+    if (ctb_log2 < 3 || ctb_log2 > 6) return HEVCDBK_ERR_ARG;
+    if (params_stride < ((p->plane_w + (1u << ctb_log2) - 1) >> ctb_log2)) return HEVCDBK_ERR_ARG;
+    if (keep && keep_stride < p->plane_w / 8) return HEVCDBK_ERR_ARG;
+    const size_t align = 4 * p->sample_bytes;
+    if (p->pitch % align != 0 || p->frame_stride % align != 0 || (uintptr_t)p->src % align != 0 || (uintptr_t)p->dst % align != 0)
+        return HEVCDBK_ERR_UNSUPPORTED;
+    if (p->pitch < (size_t)p->plane_w * p->sample_bytes || p->n_frames > 65535 || p->plane_h > 65535) return HEVCDBK_ERR_ARG;
+    if (int rc = bind(ctx)) return rc;
+    DbkSaoArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.src = (const uint8_t *)p->src; a.dst = (uint8_t *)p->dst;
+    a.pitch = (long long)p->pitch; a.frame_stride = (long long)p->frame_stride;
+    a.plane_w = (int)p->plane_w; a.plane_h = (int)p->plane_h; a.n_frames = (int)p->n_frames;
+    a.max_v = (1 << p->bit_depth) - 1; a.band_shift = (int)p->bit_depth - 5;
+    a.params = reinterpret_cast<const DbkSaoCtb *>(params);
+    a.params_stride = (int)params_stride; a.params_frame_stride = (long long)params_frame_stride;
+    a.ctb_log2 = (int)ctb_log2;
+    a.keep = keep; a.keep_stride = (int)keep_stride; a.keep_frame_stride = (long long)keep_frame_stride;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
+    return hip_ok(ctx, dbk_launch_sao(a, (int)p->sample_bytes, s), "SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+}
+
 /* ---- multi-frame .yuv file -> file: read || filter || write ---------------------------- */
 
 int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *in_name, const char *out_name, unsigned width,

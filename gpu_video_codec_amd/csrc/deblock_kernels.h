@@ -65,3 +65,25 @@ hipError_t dbk_launch_h265_bs(const void *flags, const void *mv0, const void *mv
                               int h, uint8_t *vert, uint8_t *hor, uint8_t *cvert, uint8_t *chor, hipStream_t stream);
 hipError_t dbk_launch_h265_chroma_bs(const uint8_t *vert, const uint8_t *hor, int w, int h, uint8_t *cvert, uint8_t *chor,
                                      hipStream_t stream);
+
+/* ---- sample adaptive offset (H.265 clause 8.7.3), sao.hip ---- */
+struct DbkSaoCtb {
+    uint8_t type;     /* 0 off, 1 band, 2 edge */
+    uint8_t cls;      /* band position / edge class */
+    int8_t offset[4]; /* SaoOffsetVal[1..4] */
+};
+struct DbkSaoArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    long long pitch, frame_stride;
+    int plane_w, plane_h, n_frames;
+    int max_v, band_shift; /* (1 << bit_depth) - 1, bit_depth - 5 */
+    const DbkSaoCtb *params;
+    int params_stride;
+    long long params_frame_stride; /* entries */
+    int ctb_log2;                  /* CTB size of this plane, in samples */
+    const uint8_t *keep;           /* per 8x8 samples of this plane, may be NULL */
+    int keep_stride;
+    long long keep_frame_stride;
+};
+hipError_t dbk_launch_sao(const DbkSaoArgs &a, int sample_bytes, hipStream_t stream);

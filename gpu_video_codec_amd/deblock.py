@@ -299,6 +299,12 @@ class Context:
             b.free()
         return res
 
+    def sao_device(self, planes, params_ptr, params_stride, ctb_log2, *, params_frame_stride=0, keep_ptr=None, keep_stride=0,
+                   keep_frame_stride=0):
+        """hevc_sao_filter_device: H.265 8.7.3 on planes in HBM, src -> dst."""
+        _chk(_lib.lib().hevc_sao_filter_device(self.handle, C.byref(planes), params_ptr, params_stride, params_frame_stride,
+                                               ctb_log2, keep_ptr, keep_stride, keep_frame_stride, None), self.handle)
+
     def run_timed(self, planes_list, qp, steps, *, variant=KERNEL_AUTO, tc_table=None, beta_table=None):
         """`steps` back-to-back launches of every plane in planes_list; per-step kernel ms (HIP events)."""
         arr = (_lib.DevicePlanes * len(planes_list))(*planes_list)

@@ -300,6 +300,29 @@ int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, cons
                                 const hevcdbk_bs *bs4, const hevcdbk_qp *qp, const hevcdbk_h265_params *params,
                                 hevcdbk_timing *timing);
 
+/* ==================================================================================================================
+ * Sample adaptive offset, ITU-T H.265 clause 8.7.3: the in-loop stage that follows deblocking.  Not
+ * present in the reference; parity against oracle/h265_oracle.c only ("parity unpinned").
+ * ================================================================================================================== */
+typedef struct hevcdbk_sao_ctb {
+    uint8_t type;      /* SaoTypeIdx: 0 = not applied, 1 = band offset, 2 = edge offset */
+    uint8_t cls;       /* band offset: sao_band_position (0..31); edge offset: SaoEoClass (0 hor, 1 ver, 2 135 deg, 3 45 deg) */
+    int8_t offset[4];  /* SaoOffsetVal[1..4]: signed, already scaled by log2OffsetScale */
+} hevcdbk_sao_ctb;
+
+/*
+ * SAO of planes that live in HBM, src -> dst (they must differ: the edge classifier reads deblocked neighbours).  Of
+ * `planes` the members src, dst, pitch, frame_stride, n_frames, plane_w, plane_h (multiples of 8), bit_depth and
+ * sample_bytes are used.  `params` (DEVICE memory): one entry per CTB of THIS plane, row stride params_stride entries,
+ * params_frame_stride entries between frames (0 = shared); ctb_log2 = CTB size of this plane in samples (luma 4..6, 4:2:0
+ * chroma one less: 3..5).  `keep` (DEVICE, may be NULL): one byte per 8x8 samples of this plane, non-zero = left
+ * unmodified (PCM with pcm_loop_filter_disabled_flag, cu_transquant_bypass_flag), row stride keep_stride, frame stride
+ * keep_frame_stride bytes.  Edge offset leaves a sample alone when one of its two neighbours is outside the picture.
+ */
+int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, const hevcdbk_sao_ctb *params,
+                           unsigned params_stride, size_t params_frame_stride, unsigned ctb_log2, const uint8_t *keep,
+                           unsigned keep_stride, size_t keep_frame_stride, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

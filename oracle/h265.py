@@ -137,3 +137,42 @@ def random_units(w, h, seed, *, p_intra=0.3, grid=8):
                     if size >= 2 and rng.randint(0, 2) == 0:
                         flags[y0:y1, x0 + 1] |= U_TU_LEFT
     return flags, mv0, mv1, ref0, ref1
+
+
+# ---- sample adaptive offset, clause 8.7.3 ---------------------------------------------------------------------------
+
+SAO_CTB_DTYPE = np.dtype([("type", "u1"), ("cls", "u1"), ("offset", "i1", (4,))])
+
+
+def sao_plane(plane, params, ctb_log2, *, bit_depth=8, keep=None):
+    """SAO of one un-padded plane; params = structured array (CTB rows, CTB cols) of SAO_CTB_DTYPE; returns a new array."""
+    src = np.ascontiguousarray(plane)
+    dst = np.empty_like(src)
+    h, w = src.shape
+    prm = np.ascontiguousarray(params, SAO_CTB_DTYPE)
+    assert prm.shape[0] >= (h + (1 << ctb_log2) - 1) >> ctb_log2 and prm.shape[1] >= (w + (1 << ctb_log2) - 1) >> ctb_log2
+    k = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+    rc = _lib().dbko_h265_sao_plane(
+        src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p), w, h, C.c_size_t(src.strides[0]), bit_depth, src.itemsize,
+        prm.ctypes.data_as(C.c_void_p), prm.shape[1], ctb_log2, None if k is None else k.ctypes.data_as(C.c_void_p),
+        0 if k is None else k.shape[1])
+    if rc:
+        raise RuntimeError("dbko_h265_sao_plane: %d" % rc)
+    return dst
+
+
+def random_sao_params(w, h, ctb_log2, seed, bit_depth=8):
+    rng = np.random.RandomState(seed)
+    rows, cols = (h + (1 << ctb_log2) - 1) >> ctb_log2, (w + (1 << ctb_log2) - 1) >> ctb_log2
+    p = np.zeros((rows, cols), SAO_CTB_DTYPE)
+    p["type"] = rng.randint(0, 3, (rows, cols))
+    band = p["type"] == 1
+    p["cls"] = np.where(band, rng.randint(0, 32, (rows, cols)), rng.randint(0, 4, (rows, cols)))
+    lim = (1 << (min(bit_depth, 10) - 5)) - 1
+    off = rng.randint(-lim, lim + 1, (rows, cols, 4))
+    # edge offsets: the first two are non-negative, the last two non-positive (7.4.9.3.2); band offsets keep their signs
+    eo = ~band
+    off[eo, 0:2] = np.abs(off[eo, 0:2])
+    off[eo, 2:4] = -np.abs(off[eo, 2:4])
+    p["offset"] = off
+    return p

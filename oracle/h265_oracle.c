@@ -241,3 +241,45 @@ void dbko_h265_chroma_bs(const uint8_t *vert_bs4, const uint8_t *hor_bs4, unsign
         for (unsigned m = 0; m < cw / 4; m++)
             c_hor_bs4[by * chstride + m] = hor_bs4[(size_t)(2 * by) * hstride + 2 * m];
 }
+
+/* ---- 8.7.3 ---- */
+
+static int sgn(int v) { return (v > 0) - (v < 0); }
+
+int dbko_h265_sao_plane(const void *src, void *dst, unsigned plane_w, unsigned plane_h, size_t pitch_bytes, unsigned bit_depth,
+                        unsigned sample_bytes, const dbko_sao_ctb *params, unsigned params_stride, unsigned ctb_log2,
+                        const uint8_t *keep, unsigned keep_stride)
+{
+    if (!src || !dst || !params || src == dst || plane_w == 0 || plane_h == 0) return -5;
+    if (bit_depth < 8 || bit_depth > 16 || (sample_bytes != 1 && sample_bytes != 2) || (sample_bytes == 1 && bit_depth != 8)) return -5;
+    static const int hpos[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}};   /* 8.7.3.2, Table 8-13 */
+    static const int vpos[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
+    const int max_v = (1 << bit_depth) - 1, band_shift = (int)bit_depth - 5;
+#define S_(x, y) (sample_bytes == 1 ? (int)((const uint8_t *)src)[(size_t)(y) * pitch_bytes + (x)] \
+                                    : (int)((const uint16_t *)((const uint8_t *)src + (size_t)(y) * pitch_bytes))[(x)])
+    for (int y = 0; y < (int)plane_h; y++)
+        for (int x = 0; x < (int)plane_w; x++) {
+            const dbko_sao_ctb *c = &params[((unsigned)y >> ctb_log2) * params_stride + ((unsigned)x >> ctb_log2)];
+            const int rec = S_(x, y);
+            int out = rec;
+            const int kept = keep && keep[((unsigned)y >> 3) * keep_stride + ((unsigned)x >> 3)];
+            if (!kept && c->type == 1) {
+                /* bandTable[(k + sao_band_position) & 31] = k + 1 for k = 0..3 */
+                const int k = ((rec >> band_shift) - (int)c->cls) & 31;
+                if (k < 4) out = clip3(0, max_v, rec + c->offset[k]);
+            } else if (!kept && c->type == 2) {
+                const int xa = x + hpos[c->cls & 3][0], ya = y + vpos[c->cls & 3][0];
+                const int xb = x + hpos[c->cls & 3][1], yb = y + vpos[c->cls & 3][1];
+                if (xa >= 0 && xa < (int)plane_w && ya >= 0 && ya < (int)plane_h && xb >= 0 && xb < (int)plane_w && yb >= 0 &&
+                    yb < (int)plane_h) {
+                    int e = 2 + sgn(rec - S_(xa, ya)) + sgn(rec - S_(xb, yb));
+                    if (e <= 2) e = (e == 2) ? 0 : e + 1; /* 0 -> 1, 1 -> 2, 2 -> 0 */
+                    if (e) out = clip3(0, max_v, rec + c->offset[e - 1]);
+                }
+            }
+            if (sample_bytes == 1) ((uint8_t *)dst)[(size_t)y * pitch_bytes + x] = (uint8_t)out;
+            else ((uint16_t *)((uint8_t *)dst + (size_t)y * pitch_bytes))[x] = (uint16_t)out;
+        }
+#undef S_
+    return 0;
+}

@@ -91,6 +91,26 @@ int dbko_h265_derive_bs(const dbko_h265_units *u, unsigned w, unsigned h, uint8_
 void dbko_h265_chroma_bs(const uint8_t *vert_bs4, const uint8_t *hor_bs4, unsigned w, unsigned h,
                          uint8_t *c_vert_bs4, uint8_t *c_hor_bs4);
 
+
+/* ---- sample adaptive offset, clause 8.7.3 (PARITY UNPINNED like the rest of this file) ---- */
+
+typedef struct {
+    uint8_t type;      /* SaoTypeIdx: 0 = off, 1 = band offset, 2 = edge offset */
+    uint8_t cls;       /* band offset: sao_band_position (0..31); edge offset: SaoEoClass (0 hor, 1 ver, 2 135 deg, 3 45 deg) */
+    int8_t offset[4];  /* SaoOffsetVal[1..4], already scaled (<< log2OffsetScale) and signed */
+} dbko_sao_ctb;
+
+/*
+ * SAO of one plane, src -> dst (the edge classifier reads DEBLOCKED neighbours, never offset ones).  `ctb_log2` is the CTB
+ * size of THIS plane in samples (luma 4..6, 4:2:0 chroma one less); params[(y >> ctb_log2) * params_stride + (x >> ctb_log2)].
+ * keep (may be NULL): one byte per 8x8 block of this plane's samples, row stride keep_stride; non-zero = the sample stays
+ * unmodified (pcm_loop_filter_disabled_flag with PCM, cu_transquant_bypass_flag).  Edge offset leaves a sample alone when
+ * one of its two neighbours lies outside the picture.
+ */
+int dbko_h265_sao_plane(const void *src, void *dst, unsigned plane_w, unsigned plane_h, size_t pitch_bytes, unsigned bit_depth,
+                        unsigned sample_bytes, const dbko_sao_ctb *params, unsigned params_stride, unsigned ctb_log2,
+                        const uint8_t *keep, unsigned keep_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -203,3 +203,44 @@ def test_packed_and_generic_kernels_on_awkward_geometries(ctx, h265):
                     for x in (dv, dh, dm):
                         x.free()
                     b.free()
+
+
+def test_sao_on_device(ctx, h265):
+    """hevc_sao_filter_device against the 8.7.3 oracle: 8 and 10 bit, luma-size and chroma-size CTBs, every type and
+    class, keep map, pitched planes, a batch with per-frame parameters; chained after the spec-exact deblocking."""
+    from gpu_video_codec_amd import deblock, synth
+    rng = np.random.RandomState(21)
+    for (w, h, bd, ctb_log2, pitch) in [(64, 64, 8, 4, None), (352, 288, 8, 6, 384), (136, 72, 8, 3, None), (1920, 1088, 8, 6, None),
+                                        (264, 136, 10, 5, None), (16, 8, 8, 4, None)]:
+        sb = 1 if bd == 8 else 2
+        n = 2
+        frames = np.stack([synth.blocky_plane(w, h, seed=w + i, bit_depth=bd) for i in range(n)])
+        # make neighbours differ often enough for every edge category to occur
+        frames = np.clip(frames.astype(np.int32) + rng.randint(-3, 4, frames.shape), 0, (1 << bd) - 1).astype(frames.dtype)
+        prm = np.stack([h265.random_sao_params(w, h, ctb_log2, seed=w + 10 * i, bit_depth=bd) for i in range(n)])
+        keep = (rng.randint(0, 6, (n, h // 8, w // 8)) == 0).astype(np.uint8)
+        b = deblock.DeviceBatch(ctx, w, h, n, bit_depth=bd, pitch=None if pitch is None else pitch * sb, per_frame_bs=False)
+        b.upload_all(frames, fill=0x5A if bd == 8 else 0x15A)
+        dp, dk = ctx.alloc(prm.nbytes), ctx.alloc(keep.nbytes)
+        dp.upload(prm.view(np.uint8).ravel())
+        dk.upload(keep.ravel())
+        for use_keep in (False, True):
+            ctx.sao_device(b.planes(), dp.ptr, prm.shape[2], ctb_log2, params_frame_stride=prm.shape[1] * prm.shape[2],
+                           keep_ptr=dk.ptr if use_keep else None, keep_stride=w // 8, keep_frame_stride=(h // 8) * (w // 8))
+            ctx.synchronize()
+            for f in range(n):
+                want = h265.sao_plane(frames[f], prm[f], ctb_log2, bit_depth=bd, keep=keep[f] if use_keep else None)
+                assert np.array_equal(b.download_frame(f), want), (w, h, bd, ctb_log2, use_keep, f)
+            assert w < 64 or (want != frames[n - 1]).any()
+        dp.free()
+        dk.free()
+        b.free()
+    # in place is refused (the classifier needs the un-offset neighbours)
+    from gpu_video_codec_amd import _lib
+    b = deblock.DeviceBatch(ctx, 64, 64, 1, in_place=True)
+    dp = ctx.alloc(6 * 16)
+    with pytest.raises(_lib.DeblockError) as e:
+        ctx.sao_device(b.planes(), dp.ptr, 4, 4)
+    assert e.value.code == _lib.ERR_ARG
+    dp.free()
+    b.free()

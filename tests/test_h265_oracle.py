@@ -279,3 +279,49 @@ def test_kernel_bs_derivation_equals_oracle(h265, sim):
         if w >= 64:
             vals = set(np.unique(np.concatenate([vb, hb])))
             assert {0, 1, 2} <= vals and any(v & 4 for v in vals) and any(v & 8 for v in vals)
+
+
+def test_sao_known_answers(h265):
+    """8.7.3 by hand: band table wrap-around, each edge class and category, picture borders, clipping, keep map."""
+    P = h265.SAO_CTB_DTYPE
+    plane = np.array([[10, 10, 10, 10, 10, 10, 10, 10],
+                      [10, 50, 10, 10, 10, 10, 10, 10],
+                      [10, 10, 10, 3, 10, 10, 10, 10],
+                      [10, 10, 10, 10, 10, 20, 20, 20],
+                      [10, 10, 10, 10, 10, 20, 20, 20],
+                      [10, 10, 10, 10, 10, 20, 20, 20],
+                      [250, 250, 250, 250, 10, 10, 10, 10],
+                      [250, 250, 250, 250, 10, 10, 10, 10]], np.uint8)
+    prm = np.zeros((1, 1), P)
+    # off: identity
+    assert np.array_equal(h265.sao_plane(plane, prm, 4), plane)
+    # band offset, bands of 8 values: position 31 covers bands 31, 0, 1, 2 -> values 248..255 get offset[0], 0..7 offset[1],
+    # 8..15 offset[2], 16..23 offset[3]
+    prm[0, 0] = (1, 31, (7, -2, 1, -3))
+    out = h265.sao_plane(plane, prm, 4)
+    assert out[6, 0] == 255 and out[2, 3] == 1 and out[0, 0] == 11 and out[3, 5] == 17 and out[1, 1] == 50
+    # edge class 0 (horizontal): the peak 50 is category 4 (both neighbours lower), the valley 3 category 1
+    prm[0, 0] = (2, 0, (4, 2, -2, -5))
+    out = h265.sao_plane(plane, prm, 4)
+    assert out[1, 1] == 45 and out[2, 3] == 7
+    assert out[1, 0] == 10 and out[1, 2] == 12  # (1,0): picture border -> untouched; (1,2): 50 left, 10 right -> category 2
+    assert out[3, 4] == 12 and out[3, 5] == 18   # step 10|20: low side category 2 (+2), high side category 3 (-2)
+    # class 1 (vertical): rows 0 and 7 untouched; (2,1) below the peak: upper 50, lower 10 -> category 2
+    prm[0, 0] = (2, 1, (4, 2, -2, -5))
+    out = h265.sao_plane(plane, prm, 4)
+    assert np.array_equal(out[0], plane[0]) and np.array_equal(out[7], plane[7]) and out[1, 1] == 45 and out[2, 1] == 12
+    # classes 2 and 3 use the diagonals: the peak's diagonal neighbours see it on one side only
+    prm[0, 0] = (2, 2, (4, 2, -2, -5))
+    out = h265.sao_plane(plane, prm, 4)
+    assert out[2, 2] == 12 and out[2, 0] == 10   # (2,2): a = (1,1) = 50, b = (3,3) = 10 -> category 2; (2,0) at the border
+    prm[0, 0] = (2, 3, (4, 2, -2, -5))
+    out = h265.sao_plane(plane, prm, 4)
+    assert out[2, 0] == 10 and out[1, 1] == 45 and out[2, 2] == 10
+    # keep map: the 8x8 block stays as it is
+    prm[0, 0] = (1, 31, (7, -2, 1, -3))
+    assert np.array_equal(h265.sao_plane(plane, prm, 4, keep=np.ones((1, 1), np.uint8)), plane)
+    # 10 bit: bands of 32 values, offsets up to 31, clip to 1023
+    p10 = (plane.astype(np.uint16) * 4)
+    prm[0, 0] = (1, 31, (31, -2, 1, -3))
+    out = h265.sao_plane(p10, prm, 4, bit_depth=10)
+    assert out[6, 0] == 1023 and out[0, 0] == 41 and out[2, 3] == 10
