@@ -991,6 +991,51 @@ int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p,
     return hip_ok(ctx, dbk_launch_sao(a, (int)p->sample_bytes, s), "SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
 }
 
+namespace {
+
+/* k planar 8-bit 4:2:0 frames back to back in pinned host memory: upload, filter all planes as batches, download */
+int filter_chunk(hevcdbk_context *ctx, uint8_t *host, size_t k, unsigned W, unsigned H, unsigned qp, const hevcdbk_bs *bs,
+                 const hevcdbk_tables *tables)
+{
+    const size_t ysz = (size_t)W * H, csz = ysz / 4, fb = ysz + 2 * csz;
+    const size_t nv = hevcdbk_num_vert_bs(W, H), nh = hevcdbk_num_hor_bs(W, H);
+    const size_t ncv = hevcdbk_num_vert_bs(W / 2, H / 2), nch = hevcdbk_num_hor_bs(W / 2, H / 2);
+    if (bs) {
+        if ((bs->vert != nullptr) != (bs->hor != nullptr)) return HEVCDBK_ERR_ARG;
+        if (bs->vert && (bs->n_vert != nv || bs->n_hor != nh)) return HEVCDBK_ERR_BS_SIZE;
+        if ((bs->chroma_vert != nullptr) != (bs->chroma_hor != nullptr)) return HEVCDBK_ERR_ARG;
+        if (bs->chroma_vert && (bs->n_chroma_vert != ncv || bs->n_chroma_hor != nch)) return HEVCDBK_ERR_BS_SIZE;
+    }
+    if (int rc = grow_device(ctx, ctx->dev[1], k * fb)) return rc;
+    uint8_t *d = (uint8_t *)ctx->dev[1].p;
+    hipStream_t s = ctx->compute;
+    if (int rc = stage_bs(ctx, W, H, true, bs, s)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d, host, k * fb, hipMemcpyHostToDevice, s));
+    const uint8_t *dbs = (const uint8_t *)ctx->dev_bs.p;
+    DbkArgs args[3];
+    for (int i = 0; i < 3; i++) {
+        hevcdbk_device_planes p;
+        std::memset(&p, 0, sizeof(p));
+        p.src = p.dst = d + (i == 0 ? 0 : (i == 1 ? ysz : ysz + csz));
+        p.plane_w = i ? W / 2 : W; p.plane_h = i ? H / 2 : H;
+        p.pitch = p.plane_w; p.frame_stride = fb; p.n_frames = (unsigned)k;
+        p.bit_depth = 8; p.sample_bytes = 1; p.is_chroma = i != 0;
+        p.vert_bs = i == 0 ? dbs : dbs + nv + nh;
+        p.hor_bs = i == 0 ? dbs + nv : dbs + nv + nh + ncv;
+        if (int rc = planes_to_args(&p, qp, tables, args[i])) return rc;
+    }
+    bool fused = false;
+    if (int rc = launch_frame_fused(ctx, args, 3, 1, s, &fused)) return rc;
+    if (!fused)
+        for (int i = 0; i < 3; i++)
+            if (int rc = launch(ctx, args[i], 1, i != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(host, d, k * fb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return HEVCDBK_OK;
+}
+
+} /* namespace */
+
 /* ---- multi-frame .yuv file -> file: read || filter || write ---------------------------- */
 
 int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *in_name, const char *out_name, unsigned width,
@@ -1029,8 +1074,6 @@ int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *in_name, const cha
     const auto wall0 = std::chrono::steady_clock::now();
     bool io_ok = true;
     if (rc == HEVCDBK_OK) io_ok = std::fread(buf[0], fb, frames_in(0), fi) == frames_in(0);
-    std::vector<hevcdbk_frame> fr(chunk);
-    const hevcdbk_qp q = {qp, nullptr, 0, 6};
     for (size_t c = 0; c < nchunks && rc == HEVCDBK_OK && io_ok; c++) {
         bool rd_ok = true, wr_ok = true;
         std::thread rd, wr;
@@ -1038,15 +1081,10 @@ int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *in_name, const cha
             rd = std::thread([&, c] { rd_ok = std::fread(buf[(c + 1) % 3], fb, frames_in(c + 1), fi) == frames_in(c + 1); });
         if (c >= 1)
             wr = std::thread([&, c] { wr_ok = std::fwrite(buf[(c - 1) % 3], fb, frames_in(c - 1), fo) == frames_in(c - 1); });
-        uint8_t *b = buf[c % 3];
+        /* the k frames of the chunk lie back to back (Y, U, V, Y, U, V, ...): ONE DMA in, the three planes as batches of
+         * k frames with frame stride = one file frame (one fused launch when the geometry allows), ONE DMA out */
         const size_t k = frames_in(c);
-        for (size_t i = 0; i < k; i++) {
-            std::memset(&fr[i], 0, sizeof(fr[i]));
-            fr[i].width = width; fr[i].height = height; fr[i].bit_depth = 8; fr[i].sample_bytes = 1;
-            fr[i].plane[0] = b + i * fb; fr[i].plane[1] = b + i * fb + ysz; fr[i].plane[2] = b + i * fb + ysz + csz;
-            fr[i].pitch[0] = width; fr[i].pitch[1] = width / 2; fr[i].pitch[2] = width / 2;
-        }
-        rc = hevc_deblocking_filter_sequence(ctx, fr.data(), (unsigned)k, bs, &q, tables, nullptr);
+        rc = filter_chunk(ctx, buf[c % 3], k, width, height, qp, bs, tables);
         if (rd.joinable()) rd.join();
         if (wr.joinable()) wr.join();
         io_ok = rd_ok && wr_ok;

@@ -205,9 +205,10 @@ int hevcdbk_execute_gpu(const char *input_file_name, const char *output_file_nam
  * Multi-frame planar 8-bit 4:2:0 file -> file.  The reference's reader takes exactly one frame per file
  * (cpu.h:40-45, gpu.cu:1077-1084: anything else throws "Incorrect file size"); a sequence is what a caller holds in
  * practice, so this entry accepts any whole number of frames (>= 1) and is byte-identical, frame by frame, to running
- * the reference's ReadYuvFrame -> [SetBoundaryStrenght] -> DeblockingFilter -> Save on each.  File reads, the GPU
- * pipeline of hevc_deblocking_filter_sequence, and file writes overlap, chunk by chunk, through three pinned buffers
- * (the DMA engines read and write those directly).  `bs` / `tables` as for hevc_deblocking_filter (NULL = the
+ * the reference's ReadYuvFrame -> [SetBoundaryStrenght] -> DeblockingFilter -> Save on each.  File reads, GPU work and
+ * file writes overlap, chunk by chunk, through three pinned buffers; a chunk (up to 64 frames / 64 MiB, frames back to
+ * back as in the file) moves in ONE DMA each way and its planes are filtered as batches of frames whose frame stride is
+ * one file frame -- one fused Y+U+V launch per chunk when the geometry allows.  `bs` / `tables` as for hevc_deblocking_filter (NULL = the
  * reference's defaults).  in == out is refused.  timing->pipelined_s = wall time including file I/O.
  */
 int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *input_file_name, const char *output_file_name,
