@@ -817,15 +817,15 @@ int h265_args(const hevcdbk_device_planes *planes, int c_idx, unsigned qp, const
 
 int launch_h265(hevcdbk_context *ctx, const DbkH265Args &h, int sample_bytes, bool chroma, int variant, hipStream_t s)
 {
-    const bool can_pack = dbk_packed_h265_supports(h, sample_bytes);
+    const bool can_pack = dbk_packed_h265_supports(h, sample_bytes, chroma);
     hipError_t e;
     if (variant == HEVCDBK_KERNEL_PACKED) {
         if (!can_pack) return HEVCDBK_ERR_UNSUPPORTED;
-        e = dbk_launch_packed_h265(h, chroma, s);
+        e = dbk_launch_packed_h265(h, sample_bytes, chroma, s);
     } else if (variant == HEVCDBK_KERNEL_GENERIC) {
         e = dbk_launch_h265(h, sample_bytes, chroma, s);
     } else if (variant == HEVCDBK_KERNEL_AUTO) {
-        e = can_pack ? dbk_launch_packed_h265(h, chroma, s) : dbk_launch_h265(h, sample_bytes, chroma, s);
+        e = can_pack ? dbk_launch_packed_h265(h, sample_bytes, chroma, s) : dbk_launch_h265(h, sample_bytes, chroma, s);
     } else {
         return HEVCDBK_ERR_ARG;
     }

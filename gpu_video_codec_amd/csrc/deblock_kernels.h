@@ -57,9 +57,10 @@ struct DbkH265Args {
     int beta_s, tc_bs1, tc_bs2;
 };
 hipError_t dbk_launch_h265(const DbkH265Args &h, int sample_bytes, bool chroma, hipStream_t stream); /* 32-bit arithmetic, every operand kind */
-/* packed-int16 arithmetic on the reference-mode kernels' memory path: 8-bit samples */
-bool dbk_packed_h265_supports(const DbkH265Args &h, int sample_bytes);
-hipError_t dbk_launch_packed_h265(const DbkH265Args &h, bool chroma, hipStream_t stream);
+/* packed-int16 arithmetic on the reference-mode kernels' memory path: 8-bit samples; 16-bit containers up to 11 bit
+ * (luma) / 12 bit (chroma) */
+bool dbk_packed_h265_supports(const DbkH265Args &h, int sample_bytes, bool chroma);
+hipError_t dbk_launch_packed_h265(const DbkH265Args &h, int sample_bytes, bool chroma, hipStream_t stream);
 /* 8.7.2.4 on per-4x4-unit arrays in device memory; cvert / chor (4:2:0 chroma arrays) may be NULL */
 hipError_t dbk_launch_h265_bs(const void *flags, const void *mv0, const void *mv1, const void *ref0, const void *ref1, int w,
                               int h, uint8_t *vert, uint8_t *hor, uint8_t *cvert, uint8_t *chor, hipStream_t stream);

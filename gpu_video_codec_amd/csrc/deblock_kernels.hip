@@ -19,6 +19,7 @@
 #include "deblock_kernels.h"
 #include "deblock_packed.h"
 #include "deblock_packed_h265.h"
+#include "deblock_packed16.h"
 
 namespace {
 
@@ -367,8 +368,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
  * they are (no widening needed), so twice the bytes per pixel at the same instruction count: this is
  * the variant that runs into the HBM roof (BASELINE config 5).
  */
-template <int MODE, bool NT, bool EDGE, bool QPMAP>
-__device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, int bx, bool active)
+template <int MODE, bool NT, bool EDGE, bool QPMAP, bool CHROMA = false>
+__device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, int bx, bool active,
+                                              const DbkH265Args *hx = nullptr) /* hx: MODE 2 (spec-exact) only */
 {
     const bool lv = active && bx > 0;
     const bool rv = active && bx < a.nbx - 1;
@@ -402,8 +404,29 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
 
     if constexpr (MODE == 0) {
         const dbk::BlockBs bs = load_bs_buffer<EDGE>(a, f, by, bx, active);
-        const dbk::BlockQp q = block_qp<QPMAP, false>(a, f, by, active ? bx : 0);
-        dbk::packed_filter_luma_block16(W, bs, q, a.max_v);
+        const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
+        if constexpr (CHROMA) dbk::packed_filter_chroma_block16(W, bs, q, a.max_v);
+        else dbk::packed_filter_luma_block16(W, bs, q, a.max_v);
+    } else if constexpr (MODE == 2) { /* spec-exact mode, H.265 8.7.2 */
+        int entry[4];
+        load_bs_buffer_h265<EDGE ? 2 : 0>(a, f, by, bx, active, entry);
+        dbk::H265Seg sg;
+        if constexpr (QPMAP) {
+            int qpl[4];
+            const int sc = CHROMA ? 2 : 1, bxa = active ? bx : 0;
+            dbk::h265_block_qpl(a.qp_map + (long long)f * a.map_frame_stride, a.map_stride, a.ctu_log2, sc, a.plane_w * sc,
+                                a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, hx->qp, qpl);
+            const dbk::H265Prm prm = {hx->tc_off, hx->beta_off, hx->c_qp_offset, a.shift, a.max_v};
+            dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                sg.entry[i] = entry[i];
+                sg.beta[i] = hx->beta_s;
+                sg.tc[i] = (entry[i] & dbk::kH265BsMask) == 2 ? hx->tc_bs2 : hx->tc_bs1;
+            }
+        }
+        dbk::packed_filter_block16_h265<CHROMA>(W, sg, a.max_v);
     }
 
     if constexpr (!EDGE) {
@@ -497,6 +520,25 @@ __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
     if (!wave_coords<LINEAR>(a, c)) return;
     if (c.interior) packed16_body<MODE, NT, false, QPMAP>(a, c.by, c.f, c.bx, true);
     else packed16_body<MODE, NT, true, QPMAP>(a, c.by, c.f, c.bx, c.active);
+}
+
+/* 16-bit containers: reference-exact chroma, and the spec-exact mode's luma / chroma (deblock_packed16.h) */
+template <bool LINEAR, bool QPMAP>
+__global__ __launch_bounds__(1024) void dbk_packed16c_kernel(const DbkArgs a)
+{
+    WaveCoords c;
+    if (!wave_coords<LINEAR>(a, c)) return;
+    if (c.interior) packed16_body<0, false, false, QPMAP, true>(a, c.by, c.f, c.bx, true);
+    else packed16_body<0, false, true, QPMAP, true>(a, c.by, c.f, c.bx, c.active);
+}
+template <bool CHROMA, bool LINEAR, bool QPMAP>
+__global__ __launch_bounds__(1024) void dbk_packed16_h265_kernel(const DbkH265Args h)
+{
+    const DbkArgs &a = h.base;
+    WaveCoords c;
+    if (!wave_coords<LINEAR>(a, c)) return;
+    if (c.interior) packed16_body<2, false, false, QPMAP, CHROMA>(a, c.by, c.f, c.bx, true, &h);
+    else packed16_body<2, false, true, QPMAP, CHROMA>(a, c.by, c.f, c.bx, c.active, &h);
 }
 
 /*
@@ -827,7 +869,8 @@ bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
     if (sample_bytes == 1) return a.max_v == 255;                /* 8-bit: luma and chroma */
     /* 16-bit containers: luma, and only while every intermediate fits int16: the normal filter's
      * 9*(q0-p0) - 3*(q1-p1) + 8 needs 12*max_v + 8 <= 32767, i.e. bit depth <= 11 */
-    return !chroma && a.max_v <= 2047 && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
+    /* chroma: 4*(p0-q0) + p1 - q1 + 4 needs 5*max_v + 4 <= 32767, i.e. bit depth <= 12 */
+    return a.max_v <= (chroma ? 4095 : 2047) && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
            ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0;
 }
 
@@ -857,7 +900,10 @@ template <bool NT, bool LINEAR>
 static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int mode, dim3 grid, dim3 block, hipStream_t stream)
 {
     const bool qm = a.qp_map != nullptr;
-    if (sample_bytes == 2) {
+    if (sample_bytes == 2 && chroma && mode == 0) {
+        if (qm) hipLaunchKernelGGL((dbk_packed16c_kernel<LINEAR, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((dbk_packed16c_kernel<LINEAR, false>), grid, block, 0, stream, a);
+    } else if (sample_bytes == 2) {
         if (mode == 1) hipLaunchKernelGGL((dbk_packed16_kernel<1, NT, LINEAR, false>), grid, block, 0, stream, a);
         else if (qm) hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, false>), grid, block, 0, stream, a);
@@ -968,13 +1014,17 @@ hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t str
 }
 
 /* spec-exact mode, packed kernels: 8-bit samples (luma or chroma), scalar QP or QP map */
-bool dbk_packed_h265_supports(const DbkH265Args &h, int sample_bytes)
+bool dbk_packed_h265_supports(const DbkH265Args &h, int sample_bytes, bool chroma)
 {
     const DbkArgs &a = h.base;
-    return sample_bytes == 1 && a.max_v == 255 && (unsigned long long)a.pitch * (unsigned long long)a.plane_h < (1ull << 31);
+    if ((unsigned long long)a.pitch * (unsigned long long)a.plane_h >= (1ull << 31)) return false;
+    if (sample_bytes == 1) return a.max_v == 255;
+    /* 16-bit containers: int16 intermediates hold up to 11 bit (luma) / 12 bit (chroma), see deblock_packed16.h */
+    return a.max_v <= (chroma ? 4095 : 2047) && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
+           ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0;
 }
 
-hipError_t dbk_launch_packed_h265(const DbkH265Args &h, bool chroma, hipStream_t stream)
+hipError_t dbk_launch_packed_h265(const DbkH265Args &h, int sample_bytes, bool chroma, hipStream_t stream)
 {
     if (h.base.n_frames <= 0 || h.base.nbx <= 0 || h.base.nby <= 0) return hipSuccess;
     DbkH265Args g = h;
@@ -983,19 +1033,23 @@ hipError_t dbk_launch_packed_h265(const DbkH265Args &h, bool chroma, hipStream_t
     {
         const int qp = h.qp;
         auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-        g.beta_s = dbk::h265_beta(cl(qp + h.beta_off, 0, 51));
+        const int sh = h.base.shift; /* tc' and beta' scale with the bit depth, 8.7.2.5.3 */
+        g.beta_s = dbk::h265_beta(cl(qp + h.beta_off, 0, 51)) << sh;
         if (chroma) {
             g.tc_bs1 = 0;
-            g.tc_bs2 = dbk::h265_tc(cl(dbk::h265_chroma_qp(qp + h.c_qp_offset) + 2 + h.tc_off, 0, 53));
+            g.tc_bs2 = dbk::h265_tc(cl(dbk::h265_chroma_qp(qp + h.c_qp_offset) + 2 + h.tc_off, 0, 53)) << sh;
         } else {
-            g.tc_bs1 = dbk::h265_tc(cl(qp + h.tc_off, 0, 53));
-            g.tc_bs2 = dbk::h265_tc(cl(qp + 2 + h.tc_off, 0, 53));
+            g.tc_bs1 = dbk::h265_tc(cl(qp + h.tc_off, 0, 53)) << sh;
+            g.tc_bs2 = dbk::h265_tc(cl(qp + 2 + h.tc_off, 0, 53)) << sh;
         }
     }
-#define DBK_H265_LAUNCH(C, LIN)                                                                                     \
-    do {                                                                                                            \
-        if (g.base.qp_map) hipLaunchKernelGGL((dbk_packed_h265_kernel<C, LIN, true>), grid, block, 0, stream, g);   \
-        else hipLaunchKernelGGL((dbk_packed_h265_kernel<C, LIN, false>), grid, block, 0, stream, g);                \
+#define DBK_H265_LAUNCH(C, LIN)                                                                                       \
+    do {                                                                                                              \
+        if (sample_bytes == 2) {                                                                                      \
+            if (g.base.qp_map) hipLaunchKernelGGL((dbk_packed16_h265_kernel<C, LIN, true>), grid, block, 0, stream, g); \
+            else hipLaunchKernelGGL((dbk_packed16_h265_kernel<C, LIN, false>), grid, block, 0, stream, g);            \
+        } else if (g.base.qp_map) hipLaunchKernelGGL((dbk_packed_h265_kernel<C, LIN, true>), grid, block, 0, stream, g); \
+        else hipLaunchKernelGGL((dbk_packed_h265_kernel<C, LIN, false>), grid, block, 0, stream, g);                  \
     } while (0)
     if (linear) {
         if (chroma) DBK_H265_LAUNCH(true, true);

@@ -150,9 +150,9 @@ DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], co
 }
 
 /* ---- chroma, 8.7.2.5.8: delta = Clip3(-tc, tc, (((q0 - p0) << 2) + p1 - q1 + 4) >> 3), p0 += delta, q0 -= delta ---- */
-DBK_HD void chroma_pair_h265(pk &p0, pk p1, pk &q0, pk q1, pk tc, pk mp, pk mq)
+DBK_HD void chroma_pair_h265(pk &p0, pk p1, pk &q0, pk q1, pk tc, pk mp, pk mq, int max_v = 255)
 {
-    const pk zero = splat(0), maxv = splat(255);
+    const pk zero = splat(0), maxv = splat(max_v);
     const pk d = pk_clamp((((q0 - p0) << 2) + p1 - q1 + splat(4)) >> 3, zero - tc, tc);
     const pk np0 = pk_clamp(p0 + (d & mp), zero, maxv);
     const pk nq0 = pk_clamp(q0 - (d & mq), zero, maxv);

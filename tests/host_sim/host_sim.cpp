@@ -14,6 +14,7 @@
 #define DBK_HOST_SIM 1
 #include "../../gpu_video_codec_amd/csrc/deblock_packed.h"
 #include "../../gpu_video_codec_amd/csrc/deblock_packed_h265.h"
+#include "../../gpu_video_codec_amd/csrc/deblock_packed16.h"
 #define HAVE_PACKED 1
 #else
 #define HAVE_PACKED 0
@@ -78,6 +79,19 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
                 store_block(plane, pitch_s, w, h, bx, by, v);
                 continue;
             }
+            if (packed && sizeof(T) == 2 && is_chroma) {
+                uint32_t W[8][4];
+                for (int r = 0; r < 8; r++)
+                    for (int j = 0; j < 4; j++) W[r][j] = (uint32_t)v[r][2 * j] | ((uint32_t)v[r][2 * j + 1] << 16);
+                dbk::packed_filter_chroma_block16(W, bs, q, max_v);
+                for (int r = 0; r < 8; r++)
+                    for (int j = 0; j < 4; j++) {
+                        v[r][2 * j] = W[r][j] & 0xffff;
+                        v[r][2 * j + 1] = W[r][j] >> 16;
+                    }
+                store_block(plane, pitch_s, w, h, bx, by, v);
+                continue;
+            }
             if (packed && sizeof(T) == 1) {
                 uint32_t L[8], R[8];
                 for (int r = 0; r < 8; r++) {
@@ -130,6 +144,21 @@ static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint
             dbk::load_block_bs_h265(vbs4, hbs4, bx, by, nbx, nby, w / 8 + 1, w / 4, entry);
             dbk::h265_block_qpl(map, map_stride, unit_log2, sc, w * sc, h * sc, bx * 8 - 4, by * 8 - 4, qp, qpl);
 #if HAVE_PACKED
+            if (packed && sizeof(T) == 2) {
+                uint32_t W[8][4];
+                for (int r = 0; r < 8; r++)
+                    for (int j = 0; j < 4; j++) W[r][j] = (uint32_t)v[r][2 * j] | ((uint32_t)v[r][2 * j + 1] << 16);
+                dbk::H265Seg sg;
+                if (c_idx) { dbk::h265_seg_params<true>(entry, qpl, prm, sg); dbk::packed_filter_block16_h265<true>(W, sg, prm.max_v); }
+                else { dbk::h265_seg_params<false>(entry, qpl, prm, sg); dbk::packed_filter_block16_h265<false>(W, sg, prm.max_v); }
+                for (int r = 0; r < 8; r++)
+                    for (int j = 0; j < 4; j++) {
+                        v[r][2 * j] = W[r][j] & 0xffff;
+                        v[r][2 * j + 1] = W[r][j] >> 16;
+                    }
+                store_block(plane, pitch_s, w, h, bx, by, v);
+                continue;
+            }
             if (packed && sizeof(T) == 1) {
                 uint32_t L[8], R[8];
                 for (int r = 0; r < 8; r++) {

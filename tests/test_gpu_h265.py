@@ -173,17 +173,20 @@ def test_packed_and_generic_kernels_on_awkward_geometries(ctx, h265):
     than one workgroup -> row-major map), a QP map, chroma with offsets, keep flags, pitched rows."""
     from gpu_video_codec_amd import deblock, synth, _lib
     rng = np.random.RandomState(12)
-    for (w, h, pitch) in [(8, 8, 8), (520, 24, 576), (1032, 40, 1032), (4104, 16, 4104 + 24), (504, 264, 504)]:
+    for (w, h, pitch, bd) in [(8, 8, 8, 8), (520, 24, 576, 8), (1032, 40, 1032, 8), (4104, 16, 4104 + 24, 8), (504, 264, 504, 8),
+                              (520, 24, 576, 10), (4104, 16, 4104 + 24, 11), (264, 136, 264, 10)]:
+        sb = 1 if bd == 8 else 2
         for c_idx in (0, 1):
-            y = synth.blocky_plane(w, h, seed=w + c_idx)
+            y = synth.blocky_plane(w, h, seed=w + c_idx, bit_depth=bd)
             vb, hb = rand_bs(h265, w, h, rng)
             sc = 2 if c_idx else 1
             qmap = rng.randint(24, 48, ((h * sc + 15) // 16, (w * sc + 15) // 16)).astype(np.uint8)
             for use_map in (False, True):
-                want = h265.filter_plane(y, 36, vb, hb, c_idx=c_idx, qp_map=qmap if use_map else None, unit_log2=4,
+                want = h265.filter_plane(y, 36, vb, hb, c_idx=c_idx, bit_depth=bd, qp_map=qmap if use_map else None, unit_log2=4,
                                          tc_offset_div2=2, beta_offset_div2=-1, c_qp_offset=4 if c_idx else 0)
                 for variant in (_lib.KERNEL_GENERIC, _lib.KERNEL_PACKED):
-                    b = deblock.DeviceBatch(ctx, w, h, 2, is_chroma=bool(c_idx), pitch=pitch, in_place=True, per_frame_bs=False)
+                    b = deblock.DeviceBatch(ctx, w, h, 2, bit_depth=bd, is_chroma=bool(c_idx), pitch=pitch * sb, in_place=True,
+                                            per_frame_bs=False)
                     b.upload_all(np.stack([y, y]), fill=0x77)
                     dv, dh, dm = ctx.alloc(vb.size), ctx.alloc(hb.size), ctx.alloc(qmap.size)
                     dv.upload(vb)
@@ -198,7 +201,7 @@ def test_packed_and_generic_kernels_on_awkward_geometries(ctx, h265):
                     ctx.synchronize()
                     for f in range(2):
                         full = b.download_frame(f, with_padding=True)
-                        assert np.array_equal(full[:, :w], want), (w, h, c_idx, use_map, variant, f)
+                        assert np.array_equal(full[:, :w], want), (w, h, bd, c_idx, use_map, variant, f)
                         assert (full[:, w:] == 0x77).all()
                     for x in (dv, dh, dm):
                         x.free()

@@ -555,3 +555,28 @@ def test_two_contexts_driven_from_two_host_threads(oracle):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_packed_16bit_chroma_kernel(ctx, oracle):
+    """Reference-exact chroma on 16-bit containers through the packed kernel (10 and 12 bit; 13 bit is refused), both
+    kernels against the oracle: default bS (guard quirk Q9), caller bS, a QP map, widths with partial and row-major waves."""
+    from gpu_video_codec_amd import synth, _lib
+    rng = np.random.default_rng(31)
+    for (w, h, bd) in [(8, 8, 10), (264, 72, 10), (1032, 40, 12), (4104, 24, 10), (960, 544, 12)]:
+        c = np.stack([synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30)), bit_depth=bd, dc_range=4) for _ in range(2)])
+        c[0, : h // 2, : w // 2] = rng.integers(0, 1 << bd, (h // 2, w // 2), dtype=np.uint16)
+        vb, hb = oracle.lcg_bs(w, h, 5)
+        for variant in (_lib.KERNEL_GENERIC, _lib.KERNEL_PACKED):
+            for qp in (27, 40, 51):
+                got = run_batch(ctx, c, qp, variant=variant, bit_depth=bd, is_chroma=True, bs=[(vb, hb), oracle.default_bs(w, h)])
+                assert np.array_equal(got[0], oracle.filter_plane(c[0], qp, bit_depth=bd, is_chroma=True, vert_bs=vb, hor_bs=hb)), (w, h, bd, variant, qp)
+                assert np.array_equal(got[1], oracle.filter_plane(c[1], qp, bit_depth=bd, is_chroma=True)), (w, h, bd, variant, qp)
+    qmap = synth.ctu_qp_map(2 * 264, 2 * 72, seed=3, lo=25, hi=51)
+    c = synth.blocky_plane(264, 72, seed=77, bit_depth=10, dc_range=4)
+    got = run_batch(ctx, c[None], 0, variant=_lib.KERNEL_PACKED, bit_depth=10, is_chroma=True, qp_map=qmap)
+    assert np.array_equal(got[0], oracle.filter_plane(c, 0, bit_depth=10, is_chroma=True, qp_map=qmap))
+    from gpu_video_codec_amd import deblock
+    t = synth.blocky_plane(64, 64, seed=1, bit_depth=13)
+    with pytest.raises(deblock.DeblockError) as e:
+        run_batch(ctx, t[None], 40, variant=_lib.KERNEL_PACKED, bit_depth=13, is_chroma=True)
+    assert e.value.code == _lib.ERR_UNSUPPORTED

@@ -124,6 +124,31 @@ def test_packed_16bit_luma(sim, oracle, golden_inputs):
     assert np.array_equal(got, oracle.filter_plane(y8, 30).astype(np.uint16))
 
 
+def test_packed_16bit_chroma(sim, oracle, golden_inputs):
+    """Chroma through the packed core on 16-bit containers (csrc/deblock_packed16.h): 10 and 12 bit vs the oracle, the
+    guard quirk at bx == CW/8 included, and 8-bit data in 16-bit containers vs the reference-pinned 8-bit result."""
+    if not sim.host_sim_have_packed():
+        pytest.skip("packed core not built")
+    from gpu_video_codec_amd import synth
+    rng = np.random.default_rng(22)
+    for bd in (10, 12):  # 5*max_v + 4 fits int16 up to 12 bit
+        for (w, h) in [(8, 8), (64, 48), (264, 72)]:
+            for qp in (22, 32, 45, 51):
+                c = synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30)), bit_depth=bd, dc_range=4).copy()
+                c[: max(h // 4, 1), : max(w // 4, 1)] = rng.integers(0, 1 << bd, (max(h // 4, 1), max(w // 4, 1)), dtype=np.uint16)
+                c[h // 2:, w // 2:] = (1 << bd) - 1
+                vb, hb = oracle.lcg_bs(w, h, int(rng.integers(1, 1000)))
+                got = run_sim(sim, oracle, c, qp, is_chroma=True, bit_depth=bd, vbs=vb, hbs=hb, packed=1)
+                want = oracle.filter_plane(c, qp, is_chroma=True, bit_depth=bd, vert_bs=vb, hor_bs=hb)
+                assert np.array_equal(got, want), (bd, w, h, qp)
+                got = run_sim(sim, oracle, c, qp, is_chroma=True, bit_depth=bd, packed=1)  # default bS: Q9 shifted read
+                assert np.array_equal(got, oracle.filter_plane(c, qp, is_chroma=True, bit_depth=bd)), (bd, w, h, qp)
+    _, u8, v8 = oracle.split_yuv420(golden_inputs["image2"], 768, 576)
+    for c8 in (u8, v8):
+        got = run_sim(sim, oracle, c8.astype(np.uint16), 30, is_chroma=True, bit_depth=8, packed=1)
+        assert np.array_equal(got, oracle.filter_plane(c8, 30, is_chroma=True).astype(np.uint16))
+
+
 def test_packed_with_ctu_qp_map(sim, oracle):
     """Per-segment tc/beta (the per-CTU QP map extension) through the packed core: 8-bit luma and chroma,
     10-bit luma; QPs spanning tc == 0 (QP < 18) up to QP 51 so every threshold edge case occurs."""
