@@ -179,28 +179,34 @@ DBK_HD Decision decide(const Taps &a, int beta, int tc)
 
 /* ---- filters on one line pair ------------------------------------------------------------------- */
 
-/* strong filter (cpu.h:1152-1211), c = 2*tc */
+/* strong filter (cpu.h:1152-1211), c = 2*tc.
+ *
+ * p' = clip(s, p - c, p + c) is evaluated as clip(s + c, p, p + 2c) - c: the "+ c" rides for free on the rounding
+ * constants of the sums (s0 and s1 carry the shared p0+q0+2 term twice / once under >>3 / >>2, so that term takes
+ * 2 + 4c; s2 gets the same constant once more), which removes the signed p - c of every tap and leaves max, min and
+ * two carry-free 32-bit adds per output.  All fields stay non-negative and below 2^15 (8*max_v + 4 + 8c). */
 DBK_HD void strong_pair(Taps &t, pk c)
 {
-    /* every partial sum is a sum of samples (<= 8*255+4): carry-free 32-bit adds */
-    const pk u2 = uaddc(uadd(t.p0, t.q0), 0x00020002u);
-    const pk tp = uadd(u2, t.p1);       /* p1+p0+q0+2 */
-    const pk tq = uadd(u2, t.q1);       /* q1+q0+p0+2 */
-    const pk bp = uadd(tp, t.p2);       /* p2+p1+p0+q0+2 */
+    const pk k = uaddc(uadd(uadd(c, c), uadd(c, c)), 0x00020002u); /* 2 + 4c */
+    const pk c2 = uadd(c, c);
+    const pk u2 = uadd(uadd(t.p0, t.q0), k);
+    const pk tp = uadd(u2, t.p1);       /* p1+p0+q0+2 (+4c) */
+    const pk tq = uadd(u2, t.q1);
+    const pk bp = uadd(tp, t.p2);       /* p2+p1+p0+q0+2 (+4c) */
     const pk bq = uadd(tq, t.q2);
     const pk p32 = uadd(t.p3, t.p2), q32 = uadd(t.q3, t.q2);
-    const pk s0p = uadd(uadd(tp, bp), t.q1) >> 3;                         /* (p2+2p1+2p0+2q0+q1+4)>>3 */
-    const pk s1p = bp >> 2;                                               /* (p2+p1+p0+q0+2)>>2 */
-    const pk s2p = uaddc(uadd(uadd(p32, p32), bp), 0x00020002u) >> 3;     /* (2p3+3p2+p1+p0+q0+4)>>3 */
+    const pk s0p = uadd(uadd(tp, bp), t.q1) >> 3;              /* (p2+2p1+2p0+2q0+q1+4)>>3  + c */
+    const pk s1p = bp >> 2;                                    /* (p2+p1+p0+q0+2)>>2        + c */
+    const pk s2p = uadd(uadd(uadd(p32, p32), bp), k) >> 3;     /* (2p3+3p2+p1+p0+q0+4)>>3   + c */
     const pk s0q = uadd(uadd(tq, bq), t.p1) >> 3;
     const pk s1q = bq >> 2;
-    const pk s2q = uaddc(uadd(uadd(q32, q32), bq), 0x00020002u) >> 3;
-    const pk np0 = pk_clamp(s0p, t.p0 - c, uadd(t.p0, c));
-    const pk np1 = pk_clamp(s1p, t.p1 - c, uadd(t.p1, c));
-    const pk np2 = pk_clamp(s2p, t.p2 - c, uadd(t.p2, c));
-    const pk nq0 = pk_clamp(s0q, t.q0 - c, uadd(t.q0, c));
-    const pk nq1 = pk_clamp(s1q, t.q1 - c, uadd(t.q1, c));
-    const pk nq2 = pk_clamp(s2q, t.q2 - c, uadd(t.q2, c));
+    const pk s2q = uadd(uadd(uadd(q32, q32), bq), k) >> 3;
+    const pk np0 = usub(pk_min(pk_max(s0p, t.p0), uadd(t.p0, c2)), c);
+    const pk np1 = usub(pk_min(pk_max(s1p, t.p1), uadd(t.p1, c2)), c);
+    const pk np2 = usub(pk_min(pk_max(s2p, t.p2), uadd(t.p2, c2)), c);
+    const pk nq0 = usub(pk_min(pk_max(s0q, t.q0), uadd(t.q0, c2)), c);
+    const pk nq1 = usub(pk_min(pk_max(s1q, t.q1), uadd(t.q1, c2)), c);
+    const pk nq2 = usub(pk_min(pk_max(s2q, t.q2), uadd(t.q2, c2)), c);
     t.p0 = np0; t.p1 = np1; t.p2 = np2;
     t.q0 = nq0; t.q1 = nq1; t.q2 = nq2;
 }
