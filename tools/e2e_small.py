@@ -14,8 +14,32 @@ def main():
     ap.add_argument("--qp", type=int, default=35)
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--file-frames", type=int, default=0, help="also time hevcdbk_filter_yuv_file on a file of N frames")
+    ap.add_argument("--sequence-frames", type=int, default=0, help="also time hevc_deblocking_filter_sequence on N frames")
     a = ap.parse_args()
     ctx = deblock.Context(0)
+    if a.sequence_frames:
+        base = [synth.blocky_yuv420(a.width, a.height, seed=11, frame=i) for i in range(8)]
+        for kind in ("pageable", "pinned"):
+            frames = []
+            for i in range(a.sequence_frames):
+                src = base[i % 8]
+                if kind == "pinned":
+                    pl = tuple(ctx.pinned_array(p.shape, p.dtype) for p in src)
+                    for d, s_ in zip(pl, src):
+                        d[:] = s_
+                else:
+                    pl = tuple(p.copy() for p in src)
+                frames.append(pl)
+            best = None
+            for _ in range(3):
+                t = ctx.filter_sequence(frames, qp=a.qp)
+                best = t if best is None else min(best, t)
+            print(json.dumps({"sequence_operator": {"memory": kind, "frames": a.sequence_frames, "wall_s": best,
+                                                    "frames_per_s": a.sequence_frames / best}}))
+            if kind == "pinned":
+                for pl in frames:
+                    for d in pl:
+                        ctx.free_pinned(d)
     if a.file_frames:
         import tempfile
         d = "/dev/shm" if os.path.isdir("/dev/shm") else None
