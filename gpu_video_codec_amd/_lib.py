@@ -24,7 +24,7 @@ EXPORTS = [
     "hevcdbk_device_malloc", "hevcdbk_device_free", "hevcdbk_host_malloc_pinned", "hevcdbk_host_free_pinned",
     "hevcdbk_memcpy_h2d", "hevcdbk_memcpy_d2h", "hevcdbk_memcpy_d2d", "hevcdbk_memset_d",
     "hevcdbk_synchronize", "hevcdbk_compute_stream", "hevcdbk_device_run_timed", "hevcdbk_execute_gpu",
-    "hevcdbk_filter_yuv_file",
+    "hevcdbk_filter_yuv_file", "hevcdbk_filter_yuv_file_multi",
     "hevcdbk_h265_num_vert_bs", "hevcdbk_h265_num_hor_bs", "hevcdbk_h265_derive_bs_device",
     "hevc_deblocking_filter_h265_device", "hevc_deblocking_filter_h265", "hevc_sao_filter_device",
 ]
@@ -135,6 +135,9 @@ def lib():
                                           C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int]
         L.hevcdbk_filter_yuv_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint, C.c_uint, C.c_uint,
                                               C.POINTER(Bs), C.POINTER(Tables), C.POINTER(C.c_uint), C.POINTER(Timing)]
+        L.hevcdbk_filter_yuv_file_multi.argtypes = [C.POINTER(C.c_int), C.c_uint, C.c_char_p, C.c_char_p, C.c_uint, C.c_uint,
+                                                    C.c_uint, C.POINTER(Bs), C.POINTER(Tables), C.POINTER(C.c_uint),
+                                                    C.POINTER(Timing)]
         L.hevcdbk_h265_num_vert_bs.restype = C.c_size_t
         L.hevcdbk_h265_num_hor_bs.restype = C.c_size_t
         L.hevcdbk_h265_num_vert_bs.argtypes = [C.c_uint, C.c_uint]

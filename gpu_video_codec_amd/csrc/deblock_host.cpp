@@ -11,6 +11,10 @@
  */
 #include <hip/hip_runtime_api.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -1097,6 +1101,83 @@ int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *in_name, const cha
     for (auto *b : buf) if (b) (void)hipHostFree(b);
     if (rc != HEVCDBK_OK) return rc;
     if (!io_ok) return HEVCDBK_ERR_IO;
+    if (n_frames_out) *n_frames_out = (unsigned)n;
+    if (timing) {
+        std::memset(timing, 0, sizeof(*timing));
+        timing->pipelined_s = std::chrono::duration<double>(wall1 - wall0).count();
+    }
+    return HEVCDBK_OK;
+}
+
+/* ---- the same file operator sharded over several GPUs of one node -------------------------------- */
+/*
+ * Frames are independent, so the path shards with no exchange step: chunk c of the file (up to 64 frames) belongs to
+ * worker c mod G; every worker is one host thread with its own context (= its own device, streams and staging), reads
+ * its chunks with pread, filters them, and writes them back at the same offsets with pwrite.  No collective, no
+ * xGMI traffic; the shared resources are the file system and the PCIe root complexes.
+ */
+int hevcdbk_filter_yuv_file_multi(const int *devices, unsigned n_devices, const char *in_name, const char *out_name,
+                                  unsigned width, unsigned height, unsigned qp, const hevcdbk_bs *bs,
+                                  const hevcdbk_tables *tables, unsigned *n_frames_out, hevcdbk_timing *timing)
+{
+    if (!devices || n_devices == 0 || n_devices > 64 || !in_name || !out_name || std::strcmp(in_name, out_name) == 0)
+        return HEVCDBK_ERR_ARG;
+    const int fdi = ::open(in_name, O_RDONLY);
+    if (fdi < 0) return HEVCDBK_ERR_IO;
+    struct stat st;
+    if (::fstat(fdi, &st) != 0) { ::close(fdi); return HEVCDBK_ERR_IO; }
+    const long long length = (long long)st.st_size;
+    const size_t ysz = (size_t)width * height, csz = ysz / 4, fb = ysz + 2 * csz;
+    if (fb == 0 || length <= 0 || (unsigned long long)length % fb != 0) { ::close(fdi); return HEVCDBK_ERR_FILE_SIZE; }
+    if (width % 8 != 0 || height % 8 != 0 || (width / 2) % 8 != 0 || (height / 2) % 8 != 0) { ::close(fdi); return HEVCDBK_ERR_DIMENSIONS; }
+    const unsigned long long n = (unsigned long long)length / fb;
+    if (n > 0xffffffffull) { ::close(fdi); return HEVCDBK_ERR_FILE_SIZE; }
+    const int fdo = ::open(out_name, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fdo < 0) { ::close(fdi); return HEVCDBK_ERR_IO; }
+    if (::ftruncate(fdo, (off_t)length) != 0) { ::close(fdi); ::close(fdo); return HEVCDBK_ERR_IO; }
+
+    size_t chunk = ((size_t)64 << 20) / fb;
+    chunk = chunk < 1 ? 1 : (chunk > 64 ? 64 : chunk);
+    /* at least one chunk per device when the file is long enough */
+    while (chunk > 1 && (n + chunk - 1) / chunk < n_devices) chunk = (chunk + 1) / 2;
+    const size_t nchunks = (size_t)((n + chunk - 1) / chunk);
+    std::vector<int> rcs(n_devices, HEVCDBK_OK);
+    const auto wall0 = std::chrono::steady_clock::now();
+    auto worker = [&](unsigned g) {
+        hevcdbk_context *ctx = nullptr;
+        int rc = hevcdbk_create(devices[g], &ctx);
+        uint8_t *buf = nullptr;
+        if (rc == HEVCDBK_OK && hipHostMalloc((void **)&buf, chunk * fb, hipHostMallocDefault) != hipSuccess) rc = HEVCDBK_ERR_HIP;
+        for (size_t c = g; c < nchunks && rc == HEVCDBK_OK; c += n_devices) {
+            const size_t k = (size_t)((c + 1) * chunk <= n ? chunk : n - c * chunk);
+            const off_t off = (off_t)(c * chunk * fb);
+            size_t done = 0;
+            while (done < k * fb) {
+                const ssize_t got = ::pread(fdi, buf + done, k * fb - done, off + (off_t)done);
+                if (got <= 0) { rc = HEVCDBK_ERR_IO; break; }
+                done += (size_t)got;
+            }
+            if (rc == HEVCDBK_OK) rc = filter_chunk(ctx, buf, k, width, height, qp, bs, tables);
+            done = 0;
+            while (rc == HEVCDBK_OK && done < k * fb) {
+                const ssize_t put = ::pwrite(fdo, buf + done, k * fb - done, off + (off_t)done);
+                if (put <= 0) { rc = HEVCDBK_ERR_IO; break; }
+                done += (size_t)put;
+            }
+        }
+        if (buf) (void)hipHostFree(buf);
+        if (ctx) hevcdbk_destroy(ctx);
+        rcs[g] = rc;
+    };
+    std::vector<std::thread> th;
+    for (unsigned g = 0; g < n_devices; g++) th.emplace_back(worker, g);
+    for (auto &t : th) t.join();
+    const auto wall1 = std::chrono::steady_clock::now();
+    ::close(fdi);
+    const bool closed = ::close(fdo) == 0;
+    for (int rc : rcs)
+        if (rc != HEVCDBK_OK) return rc;
+    if (!closed) return HEVCDBK_ERR_IO;
     if (n_frames_out) *n_frames_out = (unsigned)n;
     if (timing) {
         std::memset(timing, 0, sizeof(*timing));

@@ -62,6 +62,25 @@ def _tables(tc, beta):
     return t, keep
 
 
+def filter_yuv_file_multi(devices, in_name, out_name, width, height, qp, *, vert_bs=None, hor_bs=None):
+    """hevcdbk_filter_yuv_file_multi: the file operator sharded frame-parallel over `devices` (one worker thread and one
+    context per entry; no collective).  Returns (n_frames, wall seconds)."""
+    bs, keep = None, []
+    if vert_bs is not None:
+        bs = _lib.Bs()
+        for nm, arr in (("vert", vert_bs), ("hor", hor_bs)):
+            a = np.ascontiguousarray(arr, np.uint8)
+            keep.append(a)
+            setattr(bs, nm, a.ctypes.data)
+            setattr(bs, "n_" + nm, a.size)
+    dev = (C.c_int * len(devices))(*devices)
+    n, tm = C.c_uint(0), _lib.Timing()
+    rc = _lib.lib().hevcdbk_filter_yuv_file_multi(dev, len(devices), os.fsencode(in_name), os.fsencode(out_name), width, height,
+                                                  int(qp), None if bs is None else C.byref(bs), None, C.byref(n), C.byref(tm))
+    _chk(rc)
+    return n.value, tm.pipelined_s
+
+
 class DeviceBuffer:
     def __init__(self, ctx, nbytes):
         self.ctx, self.nbytes = ctx, int(nbytes)

@@ -215,6 +215,18 @@ int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *input_file_name, c
                             unsigned width, unsigned height, unsigned qp, const hevcdbk_bs *bs,
                             const hevcdbk_tables *tables, unsigned *n_frames, hevcdbk_timing *timing);
 
+/*
+ * The same operator sharded over several GPUs of one node (frames are independent, so there is no exchange
+ * step and no collective).  devices[g] is the HIP device of worker g; chunk c of the file (up to 64 frames) is read,
+ * filtered and written back at its own offset by worker c mod n_devices, each worker being one host thread with its own
+ * context.  A device may be listed more than once (two workers sharing one GPU).  The output is byte-identical to
+ * hevcdbk_filter_yuv_file's.  Error codes as there; the first failing worker's code is returned.
+ */
+int hevcdbk_filter_yuv_file_multi(const int *devices, unsigned n_devices, const char *input_file_name,
+                                  const char *output_file_name, unsigned width, unsigned height, unsigned qp,
+                                  const hevcdbk_bs *bs, const hevcdbk_tables *tables, unsigned *n_frames,
+                                  hevcdbk_timing *timing);
+
 /* ==================================================================================================================
  * Spec-exact mode: ITU-T H.265 (HEVC) clause 8.7.2.
  *

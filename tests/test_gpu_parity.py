@@ -580,3 +580,34 @@ def test_packed_16bit_chroma_kernel(ctx, oracle):
     with pytest.raises(deblock.DeblockError) as e:
         run_batch(ctx, t[None], 40, variant=_lib.KERNEL_PACKED, bit_depth=13, is_chroma=True)
     assert e.value.code == _lib.ERR_UNSUPPORTED
+
+
+def test_file_operator_sharded_over_workers(ctx, oracle, tmp_path):
+    """hevcdbk_filter_yuv_file_multi (SURVEY 8e inside the C ABI): chunks of the file go round-robin to worker threads, each
+    with its own context.  Only one GPU is visible here, so the workers share device 0 -- the sharding, offsets and
+    ownership logic are exactly what G devices run.  Output must equal the single-context operator's byte for byte."""
+    from gpu_video_codec_amd import deblock, synth
+    w, h, n = 352, 288, 150
+    frames = [oracle.join_yuv420(*synth.blocky_yuv420(w, h, seed=500 + i)) for i in range(n)]
+    src = tmp_path / "in.yuv"
+    src.write_bytes(b"".join(frames))
+    one = tmp_path / "one.yuv"
+    assert ctx.filter_yuv_file(str(src), str(one), w, h, 34)[0] == n
+    want = one.read_bytes()
+    fb = w * h * 3 // 2
+    for i in (0, 63, 64, 149):
+        assert want[i * fb:(i + 1) * fb] == oracle.filter_yuv420(frames[i], w, h, 34), i
+    for devices in ([0], [0, 0], [0, 0, 0, 0, 0]):
+        out = tmp_path / ("multi%d.yuv" % len(devices))
+        got_n, wall = deblock.filter_yuv_file_multi(devices, str(src), str(out), w, h, 34)
+        assert got_n == n and wall > 0
+        assert out.read_bytes() == want, devices
+    # caller bS travels to every worker
+    vb, hb = oracle.lcg_bs(w, h, 3)
+    deblock.filter_yuv_file_multi([0, 0], str(src), str(one), w, h, 40, vert_bs=vb, hor_bs=hb)
+    got = one.read_bytes()
+    for i in (0, 100):
+        assert got[i * fb:(i + 1) * fb] == oracle.filter_yuv420(frames[i], w, h, 40, vert_bs=vb, hor_bs=hb), i
+    # a device that does not exist fails the call
+    with pytest.raises(deblock.DeblockError):
+        deblock.filter_yuv_file_multi([0, 99], str(src), str(one), w, h, 34)
