@@ -2,7 +2,8 @@
  * hevc_deblock_main.cpp -- main.cu-shaped driver (main.cu:109-141) on top of libhevcdbk.so.
  *
  *   hevc_deblock_main [in.yuv out.yuv width height qp [device]]
- *   hevc_deblock_main --sequence in.yuv out.yuv width height qp [device]     (any number of frames in the file)
+ *   hevc_deblock_main --sequence in.yuv out.yuv width height qp [device[,device...]]   (any number of frames in the file;
+ *                                                                                    several devices = frame-parallel shard)
  *
  * Without arguments it runs the configuration main.cu ships with (main.cu:128-133:
  * mother-daughter 352x288, QP 35).  Prints the GetGpuDeviceInfo block (main.cu:92-107) and the
@@ -12,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "../../include/hevc_deblock.h"
 
@@ -49,22 +51,27 @@ int main(int argc, char **argv)
     int device = 0;
     if (argc >= 7 && std::string(argv[1]) == "--sequence") {
         /* beyond main.cu: a multi-frame file through the streaming pipeline (hevcdbk_filter_yuv_file) */
-        if (argc >= 8) device = std::atoi(argv[7]);
-        hevcdbk_context *ctx = nullptr;
-        int rc = hevcdbk_create(device, &ctx);
+        /* optional last argument: one device, or a comma-separated list = shard the file over those GPUs */
+        std::vector<int> devs;
+        if (argc >= 8) {
+            for (const char *p = argv[7]; *p;) {
+                devs.push_back(std::atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+        }
+        if (devs.empty()) devs.push_back(0);
         unsigned n = 0;
         hevcdbk_timing t;
-        if (rc == HEVCDBK_OK)
-            rc = hevcdbk_filter_yuv_file(ctx, argv[2], argv[3], (unsigned)std::atoi(argv[4]), (unsigned)std::atoi(argv[5]),
-                                         (unsigned)std::atoi(argv[6]), nullptr, nullptr, &n, &t);
+        const int rc = hevcdbk_filter_yuv_file_multi(devs.data(), (unsigned)devs.size(), argv[2], argv[3], (unsigned)std::atoi(argv[4]),
+                                                     (unsigned)std::atoi(argv[5]), (unsigned)std::atoi(argv[6]), nullptr, nullptr,
+                                                     &n, &t);
         if (rc != HEVCDBK_OK) {
             std::fprintf(stderr, "error: %s\n", hevcdbk_strerror(rc));
-            if (ctx) hevcdbk_destroy(ctx);
             return 1;
         }
-        std::printf("Frames: %u\nExecution Time with file I/O on GPU: %gs (%g frames/s)\n", n, t.pipelined_s,
-                    t.pipelined_s > 0 ? n / t.pipelined_s : 0.0);
-        hevcdbk_destroy(ctx);
+        std::printf("Frames: %u on %zu device worker(s)\nExecution Time with file I/O on GPU: %gs (%g frames/s)\n", n, devs.size(),
+                    t.pipelined_s, t.pipelined_s > 0 ? n / t.pipelined_s : 0.0);
         return 0;
     }
     if (argc >= 6) {
