@@ -130,3 +130,21 @@ def test_sharded_file_operator_argument_errors_need_no_gpu(L, tmp_path):
     odd = tmp_path / "odd.yuv"
     odd.write_bytes(b"\0" * (24 * 24 * 3 // 2))
     assert call(str(odd).encode(), 24, 24) == _lib.ERR_DIMENSIONS
+
+
+def test_header_is_plain_c_and_example_links(L, tmp_path):
+    """include/hevc_deblock.h must be usable from C (the boundary is a C ABI): the decoder-loop example is compiled as
+    strict C99 and linked against the library; without a GPU it must stop at hevcdbk_create with its own exit code."""
+    import subprocess
+    from gpu_video_codec_amd import _lib
+    src = os.path.join(ROOT, "examples", "decoder_loop.c")
+    exe = str(tmp_path / "decoder_loop")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), src,
+                           "-L", libdir, "-lhevcdbk", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    from gpu_video_codec_amd import deblock
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if deblock.device_count() > 0:
+        assert r.returncode == 0 and "deblocking and SAO on the GPU" in r.stdout, r.stderr
+    else:
+        assert r.returncode == 2 and "no CPU path" in r.stderr

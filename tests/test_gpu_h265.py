@@ -292,3 +292,19 @@ def test_random_geometry_sweep_both_modes(ctx, h265, oracle):
             dv.free()
             dh.free()
             b.free()
+
+
+def test_plain_c_decoder_loop_example(tmp_path):
+    """examples/decoder_loop.c (strict C99 against include/hevc_deblock.h): bS derivation, the three deblocking calls and
+    SAO on one 1080p picture, through the C ABI from C."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from gpu_video_codec_amd import _lib
+    exe = str(tmp_path / "decoder_loop")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "decoder_loop.c"), "-L", libdir, "-lhevcdbk", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "deblocking and SAO on the GPU" in r.stdout, (r.stdout, r.stderr)
