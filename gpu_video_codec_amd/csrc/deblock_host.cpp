@@ -113,6 +113,32 @@ bool bad_depth(unsigned bit_depth, unsigned sample_bytes)
            (sample_bytes == 1 && bit_depth != 8);
 }
 
+/* the checks every host-frame entry makes on a frame: depth, the reference's dimension rule (cpu.h:46-48, for the chroma
+ * planes as well when they are present), pitches */
+int check_frame(const hevcdbk_frame &f, bool &chroma)
+{
+    if (!f.plane[0] || bad_depth(f.bit_depth, f.sample_bytes)) return HEVCDBK_ERR_ARG;
+    const unsigned W = f.width, H = f.height;
+    if (W == 0 || H == 0 || W % 8 != 0 || H % 8 != 0) return HEVCDBK_ERR_DIMENSIONS;
+    chroma = f.plane[1] && f.plane[2];
+    if (chroma && ((W / 2) % 8 != 0 || (H / 2) % 8 != 0)) return HEVCDBK_ERR_DIMENSIONS;
+    for (int i = 0; i < (chroma ? 3 : 1); i++)
+        if (f.pitch[i] < (size_t)(i ? W / 2 : W) * f.sample_bytes) return HEVCDBK_ERR_ARG;
+    return HEVCDBK_OK;
+}
+
+/* caller bS arrays of the reference layout: both or neither of a pair, exact sizes (cpu.h:122-123) */
+int check_bs(const hevcdbk_bs *bs, unsigned W, unsigned H, bool chroma)
+{
+    if (!bs) return HEVCDBK_OK;
+    if ((bs->vert != nullptr) != (bs->hor != nullptr) || (bs->chroma_vert != nullptr) != (bs->chroma_hor != nullptr)) return HEVCDBK_ERR_ARG;
+    if (bs->vert && (bs->n_vert != hevcdbk_num_vert_bs(W, H) || bs->n_hor != hevcdbk_num_hor_bs(W, H))) return HEVCDBK_ERR_BS_SIZE;
+    if (bs->chroma_vert && (!chroma || bs->n_chroma_vert != hevcdbk_num_vert_bs(W / 2, H / 2) ||
+                            bs->n_chroma_hor != hevcdbk_num_hor_bs(W / 2, H / 2)))
+        return HEVCDBK_ERR_BS_SIZE;
+    return HEVCDBK_OK;
+}
+
 int fill_tables(DbkArgs &a, const hevcdbk_tables *tables, unsigned qp, unsigned bit_depth)
 {
     const unsigned *tc = (tables && tables->tc) ? tables->tc : k_tc_table;
@@ -491,26 +517,13 @@ int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *
 int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_bs *bs,
                            const hevcdbk_qp *qp, const hevcdbk_tables *tables, hevcdbk_timing *timing)
 {
-    if (!ctx || !frame || !qp || !frame->plane[0]) return HEVCDBK_ERR_ARG;
-    if (bad_depth(frame->bit_depth, frame->sample_bytes)) return HEVCDBK_ERR_ARG;
+    if (!ctx || !frame || !qp) return HEVCDBK_ERR_ARG;
+    bool chroma = false;
+    if (int rc = check_frame(*frame, chroma)) return rc;
     const unsigned W = frame->width, H = frame->height, sb = frame->sample_bytes;
-    if (W == 0 || H == 0 || W % 8 != 0 || H % 8 != 0) return HEVCDBK_ERR_DIMENSIONS; /* cpu.h:46-48 */
-    const bool chroma = frame->plane[1] && frame->plane[2];
-    if (chroma && ((W / 2) % 8 != 0 || (H / 2) % 8 != 0)) return HEVCDBK_ERR_DIMENSIONS;
     const int npl = chroma ? 3 : 1;
-    unsigned pw[3] = {W, W / 2, W / 2}, ph[3] = {H, H / 2, H / 2};
-    for (int i = 0; i < npl; i++)
-        if (frame->pitch[i] < (size_t)pw[i] * sb) return HEVCDBK_ERR_ARG;
-
-    /* bS sizes: cpu.h:122-123 */
-    const size_t nv = hevcdbk_num_vert_bs(W, H), nh = hevcdbk_num_hor_bs(W, H);
-    const size_t ncv = chroma ? hevcdbk_num_vert_bs(W / 2, H / 2) : 0, nch = chroma ? hevcdbk_num_hor_bs(W / 2, H / 2) : 0;
-    if (bs) {
-        if ((bs->vert != nullptr) != (bs->hor != nullptr)) return HEVCDBK_ERR_ARG;
-        if (bs->vert && (bs->n_vert != nv || bs->n_hor != nh)) return HEVCDBK_ERR_BS_SIZE;
-        if ((bs->chroma_vert != nullptr) != (bs->chroma_hor != nullptr)) return HEVCDBK_ERR_ARG;
-        if (bs->chroma_vert && (!chroma || bs->n_chroma_vert != ncv || bs->n_chroma_hor != nch)) return HEVCDBK_ERR_BS_SIZE;
-    }
+    const unsigned pw[3] = {W, W / 2, W / 2}, ph[3] = {H, H / 2, H / 2};
+    if (int rc = check_bs(bs, W, H, chroma)) return rc;
     if (int rc = bind(ctx)) return rc;
 
     /* staging (the reference allocates per call, gpu.cu:1103-1169 + 1236-1244; here it persists): the planes sit
@@ -670,27 +683,19 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
     if (n_frames == 0) return HEVCDBK_OK;
     if (qp->map) return HEVCDBK_ERR_UNSUPPORTED; /* one QP map per frame is not part of the streaming form */
     const hevcdbk_frame &f0 = frames[0];
-    if (bad_depth(f0.bit_depth, f0.sample_bytes) || !f0.plane[0]) return HEVCDBK_ERR_ARG;
+    bool chroma = false;
+    if (int rc = check_frame(f0, chroma)) return rc;
     const unsigned W = f0.width, H = f0.height, sb = f0.sample_bytes;
-    if (W == 0 || H == 0 || W % 8 != 0 || H % 8 != 0) return HEVCDBK_ERR_DIMENSIONS;
-    const bool chroma = f0.plane[1] && f0.plane[2];
-    if (chroma && ((W / 2) % 8 != 0 || (H / 2) % 8 != 0)) return HEVCDBK_ERR_DIMENSIONS;
     const int npl = chroma ? 3 : 1;
     const unsigned pw[3] = {W, W / 2, W / 2}, ph[3] = {H, H / 2, H / 2};
-    for (unsigned i = 0; i < n_frames; i++) {
+    for (unsigned i = 1; i < n_frames; i++) {
         const hevcdbk_frame &fr = frames[i];
+        bool c2 = false;
         if (fr.width != W || fr.height != H || fr.bit_depth != f0.bit_depth || fr.sample_bytes != sb) return HEVCDBK_ERR_ARG;
-        for (int k = 0; k < npl; k++)
-            if (!fr.plane[k] || fr.pitch[k] < (size_t)pw[k] * sb) return HEVCDBK_ERR_ARG;
+        if (int rc = check_frame(fr, c2)) return rc;
+        if (c2 != chroma) return HEVCDBK_ERR_ARG;
     }
-    const size_t nv = hevcdbk_num_vert_bs(W, H), nh = hevcdbk_num_hor_bs(W, H);
-    const size_t ncv = chroma ? hevcdbk_num_vert_bs(W / 2, H / 2) : 0, nch = chroma ? hevcdbk_num_hor_bs(W / 2, H / 2) : 0;
-    if (bs) {
-        if ((bs->vert != nullptr) != (bs->hor != nullptr)) return HEVCDBK_ERR_ARG;
-        if (bs->vert && (bs->n_vert != nv || bs->n_hor != nh)) return HEVCDBK_ERR_BS_SIZE;
-        if ((bs->chroma_vert != nullptr) != (bs->chroma_hor != nullptr)) return HEVCDBK_ERR_ARG;
-        if (bs->chroma_vert && (!chroma || bs->n_chroma_vert != ncv || bs->n_chroma_hor != nch)) return HEVCDBK_ERR_BS_SIZE;
-    }
+    if (int rc = check_bs(bs, W, H, chroma)) return rc;
     if (int rc = bind(ctx)) return rc;
     constexpr int K = hevcdbk_context::kSeqSlots;
     size_t row_bytes[3], plane_bytes[3];
@@ -1003,13 +1008,8 @@ int filter_chunk(hevcdbk_context *ctx, uint8_t *host, size_t k, unsigned W, unsi
 {
     const size_t ysz = (size_t)W * H, csz = ysz / 4, fb = ysz + 2 * csz;
     const size_t nv = hevcdbk_num_vert_bs(W, H), nh = hevcdbk_num_hor_bs(W, H);
-    const size_t ncv = hevcdbk_num_vert_bs(W / 2, H / 2), nch = hevcdbk_num_hor_bs(W / 2, H / 2);
-    if (bs) {
-        if ((bs->vert != nullptr) != (bs->hor != nullptr)) return HEVCDBK_ERR_ARG;
-        if (bs->vert && (bs->n_vert != nv || bs->n_hor != nh)) return HEVCDBK_ERR_BS_SIZE;
-        if ((bs->chroma_vert != nullptr) != (bs->chroma_hor != nullptr)) return HEVCDBK_ERR_ARG;
-        if (bs->chroma_vert && (bs->n_chroma_vert != ncv || bs->n_chroma_hor != nch)) return HEVCDBK_ERR_BS_SIZE;
-    }
+    const size_t ncv = hevcdbk_num_vert_bs(W / 2, H / 2);
+    if (int rc = check_bs(bs, W, H, true)) return rc;
     if (int rc = grow_device(ctx, ctx->dev[1], k * fb)) return rc;
     uint8_t *d = (uint8_t *)ctx->dev[1].p;
     hipStream_t s = ctx->compute;
