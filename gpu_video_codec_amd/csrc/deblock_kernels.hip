@@ -874,12 +874,8 @@ bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
            ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0;
 }
 
-/* development knobs: HEVCDBK_TUNE=nt selects the non-temporal variant, HEVCDBK_WG caps the workgroup width */
-static bool tune_nt()
-{
-    static const bool v = [] { const char *e = getenv("HEVCDBK_TUNE"); return e && strstr(e, "nt") != nullptr; }();
-    return v;
-}
+/* development knob: HEVCDBK_WG caps the workgroup width.  (The non-temporal load/store variants -- template parameter
+ * NT of the bodies -- measured slower on MI355X and are no longer instantiated.) */
 static int tune_wg_cap()
 {
     static const int v = [] {
@@ -970,11 +966,9 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
     dim3 grid, block;
     const bool linear = plan_packed(a, b, grid, block);
     if (linear) {
-        if (tune_nt()) launch_packed_t<true, true>(b, sample_bytes, chroma, mode, grid, block, stream);
-        else launch_packed_t<false, true>(b, sample_bytes, chroma, mode, grid, block, stream);
+        launch_packed_t<false, true>(b, sample_bytes, chroma, mode, grid, block, stream);
     } else {
-        if (tune_nt()) launch_packed_t<true, false>(b, sample_bytes, chroma, mode, grid, block, stream);
-        else launch_packed_t<false, false>(b, sample_bytes, chroma, mode, grid, block, stream);
+        launch_packed_t<false, false>(b, sample_bytes, chroma, mode, grid, block, stream);
     }
     return hipGetLastError();
 }
@@ -1008,8 +1002,7 @@ hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t str
     const int per_wg = planes[0].nbx < cap ? planes[0].nbx : cap;
     dim3 block((per_wg + 63) / 64 * 64, 1, 1);
     dim3 grid(rows, planes[0].n_frames, (planes[0].nbx + (int)block.x - 1) / (int)block.x);
-    if (tune_nt()) hipLaunchKernelGGL((dbk_packed_multi_kernel<true>), grid, block, 0, stream, m);
-    else hipLaunchKernelGGL((dbk_packed_multi_kernel<false>), grid, block, 0, stream, m);
+    hipLaunchKernelGGL((dbk_packed_multi_kernel<false>), grid, block, 0, stream, m);
     return hipGetLastError();
 }
 
