@@ -713,13 +713,14 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
     const auto wall0 = std::chrono::steady_clock::now();
     if (int rc = stage_bs(ctx, W, H, chroma, bs, ctx->h2d)) return rc;
 
+    std::vector<uint8_t> pinned((size_t)n_frames * 3, 0); /* plane k of frame i is page-locked caller memory */
     /* un-stage frame `i` (its D2H has been issued into slot i % K) */
     auto finish = [&](unsigned i) -> int {
         const int s = (int)(i % K);
         HIP_TRY(ctx, hipEventSynchronize(ctx->seq_ev[s][2]));
         hevcdbk_frame &fr = frames[i];
         for (int k = 0; k < npl; k++) {
-            if (is_pinned_host(fr.plane[k])) continue; /* the DMA wrote the caller's plane directly */
+            if (pinned[(size_t)i * 3 + k]) continue; /* the DMA wrote the caller's plane directly */
             for (unsigned r = 0; r < ph[k]; r++)
                 std::memcpy((uint8_t *)fr.plane[k] + r * fr.pitch[k], (const uint8_t *)ctx->seq_pin[s][k].p + r * row_bytes[k], row_bytes[k]);
         }
@@ -735,7 +736,8 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
         for (int k = 0; k < npl; k++) {
             const void *hsrc = fr.plane[k];
             size_t hpitch = fr.pitch[k];
-            if (!is_pinned_host(fr.plane[k])) {
+            pinned[(size_t)i * 3 + k] = is_pinned_host(fr.plane[k]); /* asked once per plane: the query is not free */
+            if (!pinned[(size_t)i * 3 + k]) {
                 if (int rc = grow_pinned(ctx, ctx->seq_pin[s][k], plane_bytes[k])) return rc;
                 for (unsigned r = 0; r < ph[k]; r++)
                     std::memcpy((uint8_t *)ctx->seq_pin[s][k].p + r * row_bytes[k], (const uint8_t *)fr.plane[k] + r * fr.pitch[k], row_bytes[k]);
@@ -764,7 +766,7 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
         for (int k = 0; k < npl; k++) {
             void *hdst = fr.plane[k];
             size_t hpitch = fr.pitch[k];
-            if (!is_pinned_host(fr.plane[k])) { hdst = ctx->seq_pin[s][k].p; hpitch = row_bytes[k]; }
+            if (!pinned[(size_t)i * 3 + k]) { hdst = ctx->seq_pin[s][k].p; hpitch = row_bytes[k]; }
             HIP_TRY(ctx, hipMemcpy2DAsync(hdst, hpitch, ctx->seq_dev[s][k].p, row_bytes[k], row_bytes[k], ph[k],
                                           hipMemcpyDeviceToHost, ctx->d2h));
         }
