@@ -661,6 +661,12 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
 /* ---- streaming host operator: H2D(n+1) || kernels(n) || D2H(n-1) ------------------------------------ */
 
 namespace {
+int filter_chunk(hevcdbk_context *ctx, uint8_t *host, size_t k, unsigned W, unsigned H, unsigned qp, const hevcdbk_bs *bs,
+                 const hevcdbk_tables *tables);
+}
+
+
+namespace {
 
 /* true when [p, p+bytes) is page-locked host memory the GPU can DMA from directly */
 bool is_pinned_host(const void *p)
@@ -697,6 +703,38 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
     }
     if (int rc = check_bs(bs, W, H, chroma)) return rc;
     if (int rc = bind(ctx)) return rc;
+    /* Small 8-bit 4:2:0 frames: per-frame DMA and launch costs outweigh the data, so the frames travel in groups -- packed
+     * back to back into one pinned chunk, ONE DMA each way and ONE batched fused launch per group (the file operator's path) */
+    {
+        const size_t fb = (size_t)W * H * 3 / 2;
+        if (chroma && sb == 1 && f0.bit_depth == 8 && fb <= ((size_t)2 << 20) && n_frames >= 4) {
+            size_t G = ((size_t)64 << 20) / fb;
+            G = G > 64 ? 64 : G;
+            if (int rc = grow_pinned(ctx, ctx->seq_pin[0][0], G * fb)) return rc;
+            uint8_t *chunk = (uint8_t *)ctx->seq_pin[0][0].p;
+            const size_t poff[3] = {0, (size_t)W * H, (size_t)W * H + (size_t)(W / 2) * (H / 2)};
+            const auto wall0 = std::chrono::steady_clock::now();
+            for (unsigned g0 = 0; g0 < n_frames; g0 += (unsigned)G) {
+                const size_t k = n_frames - g0 < G ? n_frames - g0 : G;
+                for (size_t i = 0; i < k; i++)
+                    for (int p = 0; p < 3; p++)
+                        for (unsigned r = 0; r < ph[p]; r++)
+                            std::memcpy(chunk + i * fb + poff[p] + (size_t)r * pw[p],
+                                        (const uint8_t *)frames[g0 + i].plane[p] + r * frames[g0 + i].pitch[p], pw[p]);
+                if (int rc = filter_chunk(ctx, chunk, k, W, H, qp->qp, bs, tables)) return rc;
+                for (size_t i = 0; i < k; i++)
+                    for (int p = 0; p < 3; p++)
+                        for (unsigned r = 0; r < ph[p]; r++)
+                            std::memcpy((uint8_t *)frames[g0 + i].plane[p] + r * frames[g0 + i].pitch[p],
+                                        chunk + i * fb + poff[p] + (size_t)r * pw[p], pw[p]);
+            }
+            if (timing) {
+                std::memset(timing, 0, sizeof(*timing));
+                timing->pipelined_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+            }
+            return HEVCDBK_OK;
+        }
+    }
     constexpr int K = hevcdbk_context::kSeqSlots;
     size_t row_bytes[3], plane_bytes[3];
     for (int k = 0; k < npl; k++) {

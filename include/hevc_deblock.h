@@ -134,7 +134,9 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
  * D2H of frame n-1 overlap on the context's three streams.  Planes that already are page-locked
  * (hevcdbk_host_malloc_pinned, hipHostMalloc, hipHostRegister) are DMA'd in place with no staging copy;
  * pageable planes go through the context's pinned ring.  bs / tables are shared by all frames;
- * timing->pipelined_s is the wall time of the whole sequence.  A per-CTU QP map is not accepted here.
+ * timing->pipelined_s is the wall time of the whole sequence.  A per-CTU QP map is not accepted here.  Sequences of small
+ * 8-bit 4:2:0 frames (<= 2 MiB per frame, at least 4 of them) travel in groups of up to 64 frames instead: packed back to
+ * back into one pinned chunk, one DMA each way and one batched launch per group.
  */
 int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_frame *frames, unsigned n_frames,
                                     const hevcdbk_bs *bs, const hevcdbk_qp *qp, const hevcdbk_tables *tables,
