@@ -866,6 +866,8 @@ __global__ __launch_bounds__(WG) void dbk_packed_q_kernel(const DbkArgs a)
 
 bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
 {
+    /* the packed kernels address a plane through a buffer resource with 32-bit offsets */
+    if ((unsigned long long)a.pitch * (unsigned long long)a.plane_h >= (1ull << 31)) return false;
     if (sample_bytes == 1) return a.max_v == 255;                /* 8-bit: luma and chroma */
     /* 16-bit containers: luma, and only while every intermediate fits int16: the normal filter's
      * 9*(q0-p0) - 3*(q1-p1) + 8 needs 12*max_v + 8 <= 32767, i.e. bit depth <= 11 */
