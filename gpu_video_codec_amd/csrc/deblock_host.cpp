@@ -113,6 +113,17 @@ bool bad_depth(unsigned bit_depth, unsigned sample_bytes)
            (sample_bytes == 1 && bit_depth != 8);
 }
 
+/* true when [p, p+bytes) is page-locked host memory the GPU can DMA from directly */
+bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError(); /* ordinary malloc memory: not an error for us */
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
 /* the checks every host-frame entry makes on a frame: depth, the reference's dimension rule (cpu.h:46-48, for the chroma
  * planes as well when they are present), pitches */
 int check_frame(const hevcdbk_frame &f, bool &chroma)
@@ -552,12 +563,6 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
     }
 
     const auto wall0 = std::chrono::steady_clock::now();
-    /* pack the caller's (pageable, pitched) planes into the pinned staging buffer */
-    for (int i = 0; i < npl; i++) {
-        const size_t rb = (size_t)pw[i] * sb;
-        for (unsigned r = 0; r < ph[i]; r++)
-            std::memcpy(hplane[i] + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
-    }
     DbkArgs args[3];
     void *dplane[3] = {dplane_b[0], dplane_b[1], dplane_b[2]};
 
@@ -574,6 +579,28 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
      * launch, one D2H, all on the compute stream (no cross-stream events to pay for). */
     const int sbs[3] = {(int)sb, (int)sb, (int)sb};
     const bool small = chroma && frame_bytes <= ((size_t)2 << 20) && dbk_multi_supports(args, npl, sbs);
+    /* planes in page-locked caller memory (hevcdbk_host_malloc_pinned) are DMA'd where they lie -- not for small frames,
+     * where one DMA of the packed staging buffer beats three DMAs of the caller's planes */
+    bool zc[3] = {false, false, false};
+    if (!small)
+        for (int i = 0; i < npl; i++) zc[i] = is_pinned_host(frame->plane[i]);
+    /* pack the caller's pageable, pitched planes into the pinned staging buffer */
+    for (int i = 0; i < npl; i++) {
+        if (zc[i]) continue;
+        const size_t rb = (size_t)pw[i] * sb;
+        for (unsigned r = 0; r < ph[i]; r++)
+            std::memcpy(hplane[i] + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
+    }
+    auto h2d_plane = [&](int i) -> hipError_t {
+        const size_t rb = (size_t)pw[i] * sb;
+        return zc[i] ? hipMemcpy2DAsync(dplane[i], rb, frame->plane[i], frame->pitch[i], rb, ph[i], hipMemcpyHostToDevice, ctx->h2d)
+                     : hipMemcpyAsync(dplane[i], hplane[i], plane_bytes[i], hipMemcpyHostToDevice, ctx->h2d);
+    };
+    auto d2h_plane = [&](int i) -> hipError_t {
+        const size_t rb = (size_t)pw[i] * sb;
+        return zc[i] ? hipMemcpy2DAsync(frame->plane[i], frame->pitch[i], dplane[i], rb, rb, ph[i], hipMemcpyDeviceToHost, ctx->d2h)
+                     : hipMemcpyAsync(hplane[i], dplane[i], plane_bytes[i], hipMemcpyDeviceToHost, ctx->d2h);
+    };
     if (small) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[12], 0)); /* the bS upload, if there was one */
         HIP_TRY(ctx, hipEventRecord(ev[1], ctx->compute));
@@ -586,11 +613,12 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
         HIP_TRY(ctx, hipEventRecord(ev[9], ctx->compute));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
     } else {
-        HIP_TRY(ctx, hipMemcpyAsync(dplane[0], hplane[0], plane_bytes[0], hipMemcpyHostToDevice, ctx->h2d));
+        HIP_TRY(ctx, h2d_plane(0));
         HIP_TRY(ctx, hipEventRecord(ev[1], ctx->h2d));
         if (chroma) {
             HIP_TRY(ctx, hipEventRecord(ev[2], ctx->h2d));
-            HIP_TRY(ctx, hipMemcpyAsync(dplane[1], hplane[1], plane_off[2] - plane_off[1] + plane_bytes[2], hipMemcpyHostToDevice, ctx->h2d));
+            HIP_TRY(ctx, h2d_plane(1));
+            HIP_TRY(ctx, h2d_plane(2));
             HIP_TRY(ctx, hipEventRecord(ev[3], ctx->h2d));
         }
         /* luma kernel as soon as Y + bS landed; chroma H2D keeps flowing underneath it */
@@ -608,12 +636,13 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
         /* D2H of Y overlaps the chroma kernels */
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[5], 0));
         HIP_TRY(ctx, hipEventRecord(ev[8], ctx->d2h));
-        HIP_TRY(ctx, hipMemcpyAsync(hplane[0], dplane[0], plane_bytes[0], hipMemcpyDeviceToHost, ctx->d2h));
+        HIP_TRY(ctx, d2h_plane(0));
         HIP_TRY(ctx, hipEventRecord(ev[9], ctx->d2h));
         if (chroma) {
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[7], 0));
             HIP_TRY(ctx, hipEventRecord(ev[10], ctx->d2h));
-            HIP_TRY(ctx, hipMemcpyAsync(hplane[1], dplane[1], plane_off[2] - plane_off[1] + plane_bytes[2], hipMemcpyDeviceToHost, ctx->d2h));
+            HIP_TRY(ctx, d2h_plane(1));
+            HIP_TRY(ctx, d2h_plane(2));
             HIP_TRY(ctx, hipEventRecord(ev[11], ctx->d2h));
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->d2h));
@@ -621,6 +650,7 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
     }
 
     for (int i = 0; i < npl; i++) {
+        if (zc[i]) continue;
         const size_t rb = (size_t)pw[i] * sb;
         for (unsigned r = 0; r < ph[i]; r++)
             std::memcpy((uint8_t *)frame->plane[i] + r * frame->pitch[i], hplane[i] + r * rb, rb);
@@ -665,21 +695,6 @@ int filter_chunk(hevcdbk_context *ctx, uint8_t *host, size_t k, unsigned W, unsi
                  const hevcdbk_tables *tables);
 }
 
-
-namespace {
-
-/* true when [p, p+bytes) is page-locked host memory the GPU can DMA from directly */
-bool is_pinned_host(const void *p)
-{
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-        (void)hipGetLastError(); /* ordinary malloc memory: not an error for us */
-        return false;
-    }
-    return at.type == hipMemoryTypeHost;
-}
-
-} /* namespace */
 
 extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_frame *frames, unsigned n_frames,
                                                const hevcdbk_bs *bs, const hevcdbk_qp *qp, const hevcdbk_tables *tables,

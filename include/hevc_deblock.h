@@ -122,7 +122,8 @@ typedef struct {
  * THE operator.  Replaces ReadYuvFrame::DeblockingFilter (cpu.h:134) and the body of ExecuteGpu
  * (gpu.cu:1246-1300: 7 H2D copies, 3 kernel launches, sync, 3 D2H copies) for a frame in HOST
  * memory, in place.  Staging goes through the context's pinned buffers with hipMemcpyAsync on
- * side streams.  bs / tables / timing may be NULL.
+ * side streams; planes of a large frame that already lie in page-locked memory
+ * (hevcdbk_host_malloc_pinned) are DMA'd where they lie instead.  bs / tables / timing may be NULL.
  */
 int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_bs *bs,
                            const hevcdbk_qp *qp, const hevcdbk_tables *tables,

@@ -611,3 +611,29 @@ def test_file_operator_sharded_over_workers(ctx, oracle, tmp_path):
     # a device that does not exist fails the call
     with pytest.raises(deblock.DeblockError):
         deblock.filter_yuv_file_multi([0, 99], str(src), str(one), w, h, 34)
+
+
+def test_single_frame_operator_on_page_locked_planes(ctx, oracle):
+    """A large frame whose planes live in page-locked caller memory is DMA'd where it lies (no staging copy), pitched rows
+    included; pinned and pageable planes may be mixed within one frame.  Results and untouched row padding as always."""
+    from gpu_video_codec_amd import synth
+    w, h = 1920, 1088
+    y, u, v = synth.blocky_yuv420(w, h, seed=61)
+    want = oracle.split_yuv420(oracle.filter_yuv420(oracle.join_yuv420(y, u, v), w, h, 33), w, h)
+    for mix in ((True, True, True), (True, False, True), (False, True, False)):
+        bufs, views = [], []
+        for p, pin in zip((y, u, v), mix):
+            shape = (p.shape[0], p.shape[1] + 64)
+            b = ctx.pinned_array(shape, np.uint8) if pin else np.empty(shape, np.uint8)
+            b[:] = 0x3C
+            b[:, :p.shape[1]] = p
+            bufs.append(b)
+            views.append(b[:, :p.shape[1]])
+        t = ctx.filter_frame(*views, qp=33)
+        assert t["pipelined_s"] > 0
+        for vw, wnt, b in zip(views, want, bufs):
+            assert np.array_equal(vw, wnt), mix
+            assert (b[:, -64:] == 0x3C).all(), mix
+        for b, pin in zip(bufs, mix):
+            if pin:
+                ctx.free_pinned(b)

@@ -57,6 +57,19 @@ def main():
                                                 "MBps_each_way": n * a.width * a.height * 1.5 / best * 1e-6,
                                                 "where": td}}))
     y0, u0, v0 = synth.blocky_yuv420(a.width, a.height, seed=5)
+    if a.width * a.height * 3 // 2 > (2 << 20):  # large frames: the same call on page-locked planes (DMA'd in place)
+        pl = [ctx.pinned_array(p.shape, p.dtype) for p in (y0, u0, v0)]
+        walls = []
+        for _ in range(a.reps):
+            for d, s_ in zip(pl, (y0, u0, v0)):
+                d[:] = s_
+            t0 = time.perf_counter()
+            ctx.filter_frame(*pl, qp=a.qp)
+            walls.append(time.perf_counter() - t0)
+        print(json.dumps({"single_frame_page_locked_planes": {"wall_s": float(np.median(walls[len(walls) // 4:])),
+                                                              "frames_per_s": 1.0 / float(np.median(walls[len(walls) // 4:]))}}))
+        for d in pl:
+            ctx.free_pinned(d)
     rows = []
     for _ in range(a.reps):
         y, u, v = y0.copy(), u0.copy(), v0.copy()
