@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""SAO (H.265 8.7.3) kernel rate: 64 x 3840x2160 8-bit luma in HBM, src -> dst, seeded per-CTB parameters (one third off,
+band, edge each), wall clock over back-to-back launches.  Diagnostic."""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpu_video_codec_amd import deblock, synth, _lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=100)
+    a = ap.parse_args()
+    w, h, n, bd = a.width, a.height, a.frames, a.bit_depth
+    sb = 1 if bd == 8 else 2
+    ctx = deblock.Context(0)
+    b = deblock.DeviceBatch(ctx, w, h, n, bit_depth=bd, per_frame_bs=False)
+    src = np.stack([synth.blocky_plane(w, h, seed=7, frame=i, bit_depth=bd) for i in range(4)])
+    b.upload_all(np.concatenate([src] * (n // 4 + 1))[:n])
+    rng = np.random.RandomState(5)
+    rows, cols = (h + 63) // 64, (w + 63) // 64
+    prm = np.zeros((rows, cols), np.dtype(_lib.SAO_CTB_DTYPE))
+    prm["type"] = rng.randint(0, 3, (rows, cols))
+    prm["cls"] = np.where(prm["type"] == 1, rng.randint(0, 32, (rows, cols)), rng.randint(0, 4, (rows, cols)))
+    prm["offset"] = rng.randint(-7, 8, (rows, cols, 4))
+    dp = ctx.alloc(prm.nbytes)
+    dp.upload(prm.view(np.uint8).ravel())
+    p = b.planes()
+    for _ in range(100):
+        ctx.sao_device(p, dp.ptr, cols, 6)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ctx.sao_device(p, dp.ptr, cols, 6)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    nbytes = 2 * n * w * h * sb
+    print(json.dumps({"stage": "sao", "ms_per_launch": dt * 1e3, "frames_per_s": n / dt, "GBps": nbytes / dt * 1e-9,
+                      "frac_of_8TBps": nbytes / dt / 8e12, "workload": "%dx%d %d-bit luma x %d" % (w, h, bd, n)}))
+
+
+if __name__ == "__main__":
+    main()
