@@ -566,7 +566,7 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
     DbkArgs args[3];
     void *dplane[3] = {dplane_b[0], dplane_b[1], dplane_b[2]};
 
-    /* events: 0/1 h2d(bs+Y) ; 2/3 h2d(U,V) ; 4/5 kernel Y ; 6/7 kernels U,V ; 8/9 d2h Y ; 10/11 d2h U,V */
+    /* events of the small-frame path: 0 start ; 12 bS / QP map uploaded ; 1..4 h2d ; 4..5 kernel ; 5..9 d2h */
     hipEvent_t *ev = ctx->ev;
     HIP_TRY(ctx, hipEventRecord(ev[0], ctx->h2d));
     if (int rc = stage_bs(ctx, W, H, chroma, bs, ctx->h2d)) return rc;
@@ -584,24 +584,13 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
     bool zc[3] = {false, false, false};
     if (!small)
         for (int i = 0; i < npl; i++) zc[i] = is_pinned_host(frame->plane[i]);
-    /* pack the caller's pageable, pitched planes into the pinned staging buffer */
-    for (int i = 0; i < npl; i++) {
-        if (zc[i]) continue;
-        const size_t rb = (size_t)pw[i] * sb;
-        for (unsigned r = 0; r < ph[i]; r++)
-            std::memcpy(hplane[i] + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
-    }
-    auto h2d_plane = [&](int i) -> hipError_t {
-        const size_t rb = (size_t)pw[i] * sb;
-        return zc[i] ? hipMemcpy2DAsync(dplane[i], rb, frame->plane[i], frame->pitch[i], rb, ph[i], hipMemcpyHostToDevice, ctx->h2d)
-                     : hipMemcpyAsync(dplane[i], hplane[i], plane_bytes[i], hipMemcpyHostToDevice, ctx->h2d);
-    };
-    auto d2h_plane = [&](int i) -> hipError_t {
-        const size_t rb = (size_t)pw[i] * sb;
-        return zc[i] ? hipMemcpy2DAsync(frame->plane[i], frame->pitch[i], dplane[i], rb, rb, ph[i], hipMemcpyDeviceToHost, ctx->d2h)
-                     : hipMemcpyAsync(hplane[i], dplane[i], plane_bytes[i], hipMemcpyDeviceToHost, ctx->d2h);
-    };
     if (small) {
+        /* pack the caller's pitched planes into the pinned staging buffer */
+        for (int i = 0; i < npl; i++) {
+            const size_t rb = (size_t)pw[i] * sb;
+            for (unsigned r = 0; r < ph[i]; r++)
+                std::memcpy(hplane[i] + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
+        }
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[12], 0)); /* the bS upload, if there was one */
         HIP_TRY(ctx, hipEventRecord(ev[1], ctx->compute));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[0].p, ctx->pin[0].p, frame_bytes, hipMemcpyHostToDevice, ctx->compute));
@@ -613,74 +602,105 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
         HIP_TRY(ctx, hipEventRecord(ev[9], ctx->compute));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
     } else {
-        HIP_TRY(ctx, h2d_plane(0));
-        HIP_TRY(ctx, hipEventRecord(ev[1], ctx->h2d));
-        if (chroma) {
-            HIP_TRY(ctx, hipEventRecord(ev[2], ctx->h2d));
-            HIP_TRY(ctx, h2d_plane(1));
-            HIP_TRY(ctx, h2d_plane(2));
-            HIP_TRY(ctx, hipEventRecord(ev[3], ctx->h2d));
-        }
-        /* luma kernel as soon as Y + bS landed; chroma H2D keeps flowing underneath it */
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[1], 0));
-        HIP_TRY(ctx, hipEventRecord(ev[4], ctx->compute));
+        /*
+         * Large frame: strip pipeline.  Image rows 8b-4 .. 8b+3 belong to block row b and to no other, so a plane splits
+         * into strips of whole block rows with no halo; strip s is uploaded, filtered (a launch over its block rows only)
+         * and downloaded while strip s+1 is being packed / uploaded and strip s-1 downloaded: the two DMA directions, the
+         * kernels and the host-side staging copies all overlap inside ONE frame.
+         */
+        struct Strip { int plane, b0, b1; unsigned r0, r1; };
+        std::vector<Strip> strips;
         for (int i = 0; i < npl; i++) {
-            if (i == 1) {
-                HIP_TRY(ctx, hipEventRecord(ev[5], ctx->compute));
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[3], 0));
-                HIP_TRY(ctx, hipEventRecord(ev[6], ctx->compute));
+            const size_t rb = (size_t)pw[i] * sb;
+            const int nby = (int)(ph[i] / 8 + 1);
+            /* strips of about 2 MiB when a host-side staging copy rides along, 4 MiB when the DMA engines work alone */
+            int per = (int)((((size_t)(zc[i] ? 4 : 2) << 20) / rb) / 8);
+            per = per < 1 ? 1 : per;
+            for (int b0 = 0; b0 < nby; b0 += per) {
+                const int b1 = b0 + per < nby ? b0 + per : nby;
+                const unsigned r0 = b0 == 0 ? 0u : (unsigned)(8 * b0 - 4), r1 = b1 == nby ? ph[i] : (unsigned)(8 * b1 - 4);
+                strips.push_back({i, b0, b1, r0, r1});
             }
-            if (int rc = launch(ctx, args[i], (int)sb, i != 0, HEVCDBK_KERNEL_AUTO, ctx->compute)) return rc;
         }
-        HIP_TRY(ctx, hipEventRecord(chroma ? ev[7] : ev[5], ctx->compute));
-        /* D2H of Y overlaps the chroma kernels */
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[5], 0));
-        HIP_TRY(ctx, hipEventRecord(ev[8], ctx->d2h));
-        HIP_TRY(ctx, d2h_plane(0));
-        HIP_TRY(ctx, hipEventRecord(ev[9], ctx->d2h));
-        if (chroma) {
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[7], 0));
-            HIP_TRY(ctx, hipEventRecord(ev[10], ctx->d2h));
-            HIP_TRY(ctx, d2h_plane(1));
-            HIP_TRY(ctx, d2h_plane(2));
-            HIP_TRY(ctx, hipEventRecord(ev[11], ctx->d2h));
+        const size_t need = 6 * strips.size();
+        while (ctx->timed_events.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->timed_events.push_back(e);
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->d2h));
+        hipEvent_t *te = ctx->timed_events.data(); /* per strip: h2d start/end, kernel start/end, d2h start/end */
+        for (size_t k = 0; k < strips.size(); k++) {
+            const Strip &st = strips[k];
+            const int i = st.plane;
+            const size_t rb = (size_t)pw[i] * sb, off = (size_t)st.r0 * rb, bytes = (size_t)(st.r1 - st.r0) * rb;
+            if (!zc[i])
+                for (unsigned r = st.r0; r < st.r1; r++)
+                    std::memcpy(hplane[i] + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
+            if (timing) HIP_TRY(ctx, hipEventRecord(te[6 * k + 0], ctx->h2d));
+            if (zc[i])
+                HIP_TRY(ctx, hipMemcpy2DAsync((uint8_t *)dplane[i] + off, rb, (const uint8_t *)frame->plane[i] + (size_t)st.r0 * frame->pitch[i],
+                                              frame->pitch[i], rb, st.r1 - st.r0, hipMemcpyHostToDevice, ctx->h2d));
+            else
+                HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)dplane[i] + off, hplane[i] + off, bytes, hipMemcpyHostToDevice, ctx->h2d));
+            HIP_TRY(ctx, hipEventRecord(te[6 * k + 1], ctx->h2d));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, te[6 * k + 1], 0));
+            if (timing) HIP_TRY(ctx, hipEventRecord(te[6 * k + 2], ctx->compute));
+            DbkArgs sa = args[i];
+            sa.by_begin = st.b0;
+            sa.by_count = st.b1 - st.b0;
+            if (int rc = launch(ctx, sa, (int)sb, i != 0, HEVCDBK_KERNEL_AUTO, ctx->compute)) return rc;
+            HIP_TRY(ctx, hipEventRecord(te[6 * k + 3], ctx->compute));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, te[6 * k + 3], 0));
+            if (timing) HIP_TRY(ctx, hipEventRecord(te[6 * k + 4], ctx->d2h));
+            if (zc[i])
+                HIP_TRY(ctx, hipMemcpy2DAsync((uint8_t *)frame->plane[i] + (size_t)st.r0 * frame->pitch[i], frame->pitch[i],
+                                              (uint8_t *)dplane[i] + off, rb, rb, st.r1 - st.r0, hipMemcpyDeviceToHost, ctx->d2h));
+            else
+                HIP_TRY(ctx, hipMemcpyAsync(hplane[i] + off, (uint8_t *)dplane[i] + off, bytes, hipMemcpyDeviceToHost, ctx->d2h));
+            HIP_TRY(ctx, hipEventRecord(te[6 * k + 5], ctx->d2h));
+        }
+        /* un-stage each strip as soon as its download has landed */
+        for (size_t k = 0; k < strips.size(); k++) {
+            const Strip &st = strips[k];
+            const int i = st.plane;
+            HIP_TRY(ctx, hipEventSynchronize(te[6 * k + 5]));
+            if (zc[i]) continue;
+            const size_t rb = (size_t)pw[i] * sb;
+            for (unsigned r = st.r0; r < st.r1; r++)
+                std::memcpy((uint8_t *)frame->plane[i] + r * frame->pitch[i], hplane[i] + r * rb, rb);
+        }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
+        const auto wall1s = std::chrono::steady_clock::now();
+        if (timing) {
+            double copy = 0.0, exec = 0.0;
+            for (size_t k = 0; k < strips.size(); k++) {
+                float ms = 0.f;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, te[6 * k + 0], te[6 * k + 1])); copy += ms;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, te[6 * k + 2], te[6 * k + 3])); exec += ms;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, te[6 * k + 4], te[6 * k + 5])); copy += ms;
+            }
+            timing->exec_s = exec * 1e-3;   /* the reference's figures are sums of its serial phases (gpu.cu:1292-1303) */
+            timing->copy_s = copy * 1e-3;
+            timing->total_s = timing->exec_s + timing->copy_s;
+            timing->pipelined_s = std::chrono::duration<double>(wall1s - wall0).count();
+        }
+        return HEVCDBK_OK;
     }
 
+    /* small frame: un-stage, and the reference's three figures from the events around its three steps */
     for (int i = 0; i < npl; i++) {
-        if (zc[i]) continue;
         const size_t rb = (size_t)pw[i] * sb;
         for (unsigned r = 0; r < ph[i]; r++)
             std::memcpy((uint8_t *)frame->plane[i] + r * frame->pitch[i], hplane[i] + r * rb, rb);
     }
     const auto wall1 = std::chrono::steady_clock::now();
-
-    if (timing && small) {
+    if (timing) {
         float ms = 0.f;
         double copy = 0.0;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[1], ev[4])); copy += ms;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[5], ev[9])); copy += ms;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[4], ev[5]));
         timing->exec_s = ms * 1e-3;
-        timing->copy_s = copy * 1e-3;
-        timing->total_s = timing->exec_s + timing->copy_s; /* gpu.cu:1302 */
-        timing->pipelined_s = std::chrono::duration<double>(wall1 - wall0).count();
-        return HEVCDBK_OK;
-    }
-    if (timing) {
-        float ms = 0.f;
-        double copy = 0.0, exec = 0.0;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[0], ev[1])); copy += ms;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[8], ev[9])); copy += ms;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[4], ev[5])); exec += ms;
-        if (chroma) {
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[2], ev[3])); copy += ms;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[10], ev[11])); copy += ms;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[6], ev[7])); exec += ms;
-        }
-        timing->exec_s = exec * 1e-3;
         timing->copy_s = copy * 1e-3;
         timing->total_s = timing->exec_s + timing->copy_s; /* gpu.cu:1302 */
         timing->pipelined_s = std::chrono::duration<double>(wall1 - wall0).count();

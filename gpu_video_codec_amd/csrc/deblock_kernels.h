@@ -29,6 +29,9 @@ struct DbkArgs {
     int use_queue;   /* 8-bit luma: strong segments scheduled through the workgroup's LDS queue */
     int diag_ablate; /* diagnostic: 1 = strong segments filtered as normal, 2 = normal filter skipped (wrong pixels) */
     int diag_xshift; /* diagnostic copy mode only: byte shift of every row span (alignment experiments) */
+    /* launch only the block rows by_begin .. by_begin + by_count - 1 (by_count 0 = all): a frame's block rows are
+     * independent, so a host pipeline can filter a frame strip by strip while the other strips are still on the bus */
+    int by_begin, by_count;
 };
 
 /* one lane per offset block, 32-bit arithmetic; every operand kind */

@@ -61,9 +61,9 @@ __global__ __launch_bounds__(256) void dbk_generic_kernel(const DbkArgs a)
     using Q = Quad<T>;
     using W = typename Q::W;
     const int bx = blockIdx.x * 64 + threadIdx.x;
-    const int by = blockIdx.y * 4 + threadIdx.y;
+    const int by = blockIdx.y * 4 + threadIdx.y + a.by_begin;
     const int f = blockIdx.z;
-    if (bx >= a.nbx || by >= a.nby) return;
+    if (bx >= a.nbx || by >= (a.by_count ? a.by_begin + a.by_count : a.nby)) return;
 
     const uint8_t *src = a.src + (long long)f * a.frame_stride;
     uint8_t *dst = a.dst + (long long)f * a.frame_stride;
@@ -122,7 +122,7 @@ template <typename T, bool CHROMA>
 hipError_t launch_generic_t(const DbkArgs &a, hipStream_t stream)
 {
     dim3 block(64, 4, 1);
-    dim3 grid((a.nbx + 63) / 64, (a.nby + 3) / 4, a.n_frames);
+    dim3 grid((a.nbx + 63) / 64, ((a.by_count ? a.by_count : a.nby) + 3) / 4, a.n_frames);
     if (a.qp_map)
         hipLaunchKernelGGL((dbk_generic_kernel<T, CHROMA, true>), grid, block, 0, stream, a);
     else
@@ -477,7 +477,7 @@ __device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
 {
     const int lane = (int)(threadIdx.x & 63u);
     if constexpr (!LINEAR) {
-        c.by = blockIdx.x;
+        c.by = (int)blockIdx.x + a.by_begin;
         c.f = blockIdx.y;
         c.bx = blockIdx.z * (int)blockDim.x + (int)threadIdx.x;
         const int wave_bx0 = __builtin_amdgcn_readfirstlane(c.bx) & ~63;
@@ -935,7 +935,8 @@ static bool plan_packed(const DbkArgs &a, DbkArgs &b, dim3 &grid, dim3 &block)
      * (3.96 vs 3.69 TB/s at 4K 8-bit, idle lanes included); wider rows (8K: 961 blocks) do better row-major
      * (5.06 vs 4.89 TB/s at 8K 10-bit).  HEVCDBK_TUNE=rowmap / linear force either for A/B runs. */
     const char *tune = getenv("HEVCDBK_TUNE");
-    const bool want_linear = (tune && strstr(tune, "linear")) || (!tune_rowmap() && a.nbx > cap);
+    /* a block-row range (strip launches of the host pipeline) always takes the row map */
+    const bool want_linear = a.by_count == 0 && ((tune && strstr(tune, "linear")) || (!tune_rowmap() && a.nbx > cap));
     const bool linear = want_linear && wpf >= 2 && a.nbx >= 2 && (nb + 1024) * a.nbx < (1ll << 32) &&
                         total * wpf < (1ll << 32) && total < (1ll << 31);
     if (linear) {
@@ -951,7 +952,7 @@ static bool plan_packed(const DbkArgs &a, DbkArgs &b, dim3 &grid, dim3 &block)
     /* small planes / degenerate divisors: one workgroup per block row, wider rows split into cap-lane chunks */
     const int per_wg = a.nbx < cap ? a.nbx : cap;
     block = dim3((per_wg + 63) / 64 * 64, 1, 1);
-    grid = dim3(a.nby, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
+    grid = dim3(a.by_count ? a.by_count : a.nby, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
     return false;
 }
 

@@ -140,7 +140,7 @@ class Context:
     # -- hevc_deblocking_filter(frame, bS, QP, tables): host planes, in place --------------------
     def filter_frame(self, y, u=None, v=None, *, qp, bit_depth=8, vert_bs=None, hor_bs=None,
                      chroma_vert_bs=None, chroma_hor_bs=None, qp_map=None, ctu_log2=6,
-                     tc_table=None, beta_table=None, check_sizes=True):
+                     tc_table=None, beta_table=None, check_sizes=True, want_timing=True):
         """Filters the given 2-D numpy planes IN PLACE (they must be writable, C-contiguous rows).
         Returns the reference's timing triple as a dict."""
         sample_bytes = y.dtype.itemsize
@@ -171,7 +171,8 @@ class Context:
         t, k2 = _tables(tc_table, beta_table)
         tm = _lib.Timing()
         rc = _lib.lib().hevc_deblocking_filter(self.handle, C.byref(fr), None if bs is None else C.byref(bs),
-                                               C.byref(q), None if t is None else C.byref(t), C.byref(tm))
+                                               C.byref(q), None if t is None else C.byref(t),
+                                               C.byref(tm) if want_timing else None)
         _chk(rc, self.handle)
         return {"exec_s": tm.exec_s, "total_s": tm.total_s, "copy_s": tm.copy_s, "pipelined_s": tm.pipelined_s}
 
