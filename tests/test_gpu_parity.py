@@ -637,3 +637,23 @@ def test_single_frame_operator_on_page_locked_planes(ctx, oracle):
         for b, pin in zip(bufs, mix):
             if pin:
                 ctx.free_pinned(b)
+
+
+def test_strip_pipeline_on_large_frames_all_kernels(ctx, oracle):
+    """Frames large enough for several strips per plane through hevc_deblocking_filter: 8-bit (packed kernels), 10-bit
+    (packed 16-bit kernels) and 12-bit (32-bit kernels), caller luma bS and a per-CTU QP map -- the block-row range
+    launches of every kernel family must reproduce the whole-plane result."""
+    from gpu_video_codec_amd import synth
+    w, h = 1920, 1088
+    for bd in (8, 10, 12):
+        y, u, v = synth.blocky_yuv420(w, h, seed=70 + bd, bit_depth=bd)
+        vb, hb = oracle.lcg_bs(w, h, bd)
+        for qmap in (None, synth.ctu_qp_map(w, h, seed=bd, lo=24, hi=46)):
+            qp = 0 if qmap is not None else 37
+            want = [oracle.filter_plane(y, qp, bit_depth=bd, vert_bs=vb, hor_bs=hb, qp_map=qmap),
+                    oracle.filter_plane(u, qp, bit_depth=bd, is_chroma=True, qp_map=qmap),
+                    oracle.filter_plane(v, qp, bit_depth=bd, is_chroma=True, qp_map=qmap)]
+            gy, gu, gv = y.copy(), u.copy(), v.copy()
+            ctx.filter_frame(gy, gu, gv, qp=qp, bit_depth=bd, vert_bs=vb, hor_bs=hb, qp_map=qmap)
+            for g, wnt, nm in zip((gy, gu, gv), want, "YUV"):
+                assert np.array_equal(g, wnt), (bd, qmap is not None, nm)
