@@ -148,3 +148,23 @@ def test_header_is_plain_c_and_example_links(L, tmp_path):
         assert r.returncode == 0 and "deblocking and SAO on the GPU" in r.stdout, r.stderr
     else:
         assert r.returncode == 2 and "no CPU path" in r.stderr
+
+
+def test_cpp_class_mirror_compiles_and_keeps_the_reference_errors(L, tmp_path):
+    """include/hevc_deblock.hpp (the ReadYuvFrame surface in C++): builds warning-free, and the reference's two constructor
+    checks throw the reference's texts before any device is needed (cpu.h:43-48)."""
+    import subprocess
+    from gpu_video_codec_amd import _lib
+    exe = str(tmp_path / "ryf")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "read_yuv_frame.cpp"), "-L", libdir, "-lhevcdbk", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    img = os.path.join(ROOT, "tests", "golden", "image1_352x288_yv12.yuv")
+    out = str(tmp_path / "o.yuv")
+    r = subprocess.run([exe, img, out, "352", "280", "30"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Incorrect file size" in r.stderr
+    odd = tmp_path / "odd.yuv"
+    odd.write_bytes(b"\0" * (12 * 8 * 3 // 2))
+    r = subprocess.run([exe, str(odd), out, "12", "8", "30"], capture_output=True, text=True)
+    assert r.returncode == 1 and "multiplier of sample block size" in r.stderr

@@ -657,3 +657,28 @@ def test_strip_pipeline_on_large_frames_all_kernels(ctx, oracle):
             ctx.filter_frame(gy, gu, gv, qp=qp, bit_depth=bd, vert_bs=vb, hor_bs=hb, qp_map=qmap)
             for g, wnt, nm in zip((gy, gu, gv), want, "YUV"):
                 assert np.array_equal(g, wnt), (bd, qmap is not None, nm)
+
+
+def test_cpp_class_mirror_against_golden_manifest(manifest, tmp_path):
+    """examples/read_yuv_frame.cpp = the reference's ExecuteCpu body on hevcdbk::ReadYuvFrame (include/hevc_deblock.hpp):
+    ctor -> [SetBoundaryStrenght with the seeded generator] -> DeblockingFilter -> Save, against the reference's own hashes."""
+    import subprocess
+    from conftest import ROOT
+    from gpu_video_codec_amd import _lib
+    exe = str(tmp_path / "ryf")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "read_yuv_frame.cpp"),
+                           "-L", libdir, "-lhevcdbk", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    files = {"image1": "image1_352x288_yv12.yuv", "mother-daughter": "mother-daughter_352x288_yv12.yuv", "image2": "image2_768x576.yuv"}
+    checked = 0
+    for name, ent in manifest["images"].items():
+        for c in ent["cases"][::4]:
+            out = tmp_path / "o.yuv"
+            cmd = [exe, os.path.join(GOLDEN, files[name]), str(out), str(ent["width"]), str(ent["height"]), str(c["qp"])]
+            if c["bs_seed"] is not None:
+                cmd.append(str(c["bs_seed"]))
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, (cmd, r.stderr)
+            assert sha256(out.read_bytes()) == c["sha256"], (name, c)
+            checked += 1
+    assert checked >= 12
