@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Randomised soak of the HIP path against the oracles (run by hand on a GPU box; not collected by pytest):
+   python tests/soak_gpu.py [--cases 400] [--seed 1]
+Every case draws a geometry, bit depth, plane kind, QP (scalar or map), bS arrays, frame count, in-place or not, and runs
+both kernels of the reference-exact mode and of the spec-exact mode; any mismatch prints the case and exits non-zero."""
+import argparse, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpu_video_codec_amd import deblock, synth, _lib
+from oracle import oracle, h265
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=400)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = np.random.RandomState(a.seed)
+    ctx = deblock.Context(0)
+    bad = 0
+    for case in range(a.cases):
+        w = int(8 * rng.choice([rng.randint(1, 20), rng.randint(60, 70), rng.randint(125, 135), rng.randint(1, 600)]))
+        h = int(8 * rng.randint(1, 24))
+        bd = int(rng.choice([8, 8, 8, 10, 11, 12]))
+        chroma = bool(rng.randint(0, 2))
+        n = int(rng.randint(1, 4))
+        in_place = bool(rng.randint(0, 2))
+        qp = int(rng.randint(16, 56))
+        use_map = rng.randint(0, 4) == 0
+        sc = 2 if chroma else 1
+        frames = np.stack([synth.blocky_plane(w, h, seed=int(rng.randint(1, 1 << 30)), bit_depth=bd) for _ in range(n)])
+        if rng.randint(0, 3) == 0:  # rough content: more clipping, more 'off' segments
+            frames = np.clip(frames.astype(np.int64) + rng.randint(-40, 41, frames.shape) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(frames.dtype)
+        qmap = None
+        if use_map:
+            qmap = rng.randint(max(qp - 10, 0), min(qp + 10, 51) + 1, ((h * sc + 63) // 64, (w * sc + 63) // 64)).astype(np.uint8)
+        rvb, rhb = oracle.lcg_bs(w, h, int(rng.randint(1, 1000))) if rng.randint(0, 2) else oracle.default_bs(w, h)
+        tag = dict(case=case, w=w, h=h, bd=bd, chroma=chroma, n=n, in_place=in_place, qp=qp, use_map=use_map)
+        want_ref = [oracle.filter_plane(frames[f], 0 if use_map else min(qp, 60), is_chroma=chroma, bit_depth=bd, vert_bs=rvb, hor_bs=rhb,
+                                        qp_map=qmap) for f in range(n)]
+        vb = (rng.randint(0, 3, h265.num_vert_bs(w, h)) | (rng.randint(0, 10, h265.num_vert_bs(w, h)) == 0) * 4).astype(np.uint8)
+        hb = (rng.randint(0, 3, h265.num_hor_bs(w, h)) | (rng.randint(0, 10, h265.num_hor_bs(w, h)) == 0) * 8).astype(np.uint8)
+        offs = dict(tc_offset_div2=int(rng.randint(-6, 7)), beta_offset_div2=int(rng.randint(-6, 7)))
+        cq = int(rng.randint(-12, 13))
+        qp_s = min(qp, 51)
+        smap = None if qmap is None else np.repeat(np.repeat(qmap, 8, 0), 8, 1)[: (h * sc + 7) // 8, : (w * sc + 7) // 8].copy()
+        want_spec = [h265.filter_plane(frames[f], qp_s, vb, hb, c_idx=1 if chroma else 0, bit_depth=bd, qp_map=smap, unit_log2=3,
+                                       c_qp_offset=cq if chroma else 0, **offs) for f in range(n)]
+        for variant in (_lib.KERNEL_GENERIC, _lib.KERNEL_PACKED):
+            b = deblock.DeviceBatch(ctx, w, h, n, bit_depth=bd, is_chroma=chroma, in_place=in_place, per_frame_bs=False)
+            try:
+                b.upload_all(frames)
+                b.set_bs(0, rvb, rhb)
+                if qmap is not None:
+                    b.set_qp_map(qmap, 6)
+                try:
+                    ctx.filter_device(b.planes(), 0 if use_map else qp, variant=variant)
+                    ctx.synchronize()
+                    for f in range(n):
+                        if not np.array_equal(b.download_frame(f), want_ref[f]):
+                            print("MISMATCH ref", variant, f, tag)
+                            bad += 1
+                except deblock.DeblockError as e:
+                    if e.code != _lib.ERR_UNSUPPORTED:
+                        raise
+                b.upload_all(frames)
+                dv, dh = ctx.alloc(vb.size), ctx.alloc(hb.size)
+                dv.upload(vb)
+                dh.upload(hb)
+                p = b.planes()
+                p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
+                dm = None
+                if smap is not None:
+                    dm = ctx.alloc(smap.size)
+                    dm.upload(smap)
+                    p.qp_map, p.qp_map_stride, p.ctu_log2, p.qp_map_frame_stride = dm.ptr, smap.shape[1], 3, 0
+                else:
+                    p.qp_map = None
+                try:
+                    ctx.filter_device_h265(p, qp_s, c_idx=1 if chroma else 0, cb_qp_offset=cq, variant=variant, **offs)
+                    ctx.synchronize()
+                    for f in range(n):
+                        if not np.array_equal(b.download_frame(f), want_spec[f]):
+                            print("MISMATCH spec", variant, f, tag, offs, cq)
+                            bad += 1
+                except deblock.DeblockError as e:
+                    if e.code != _lib.ERR_UNSUPPORTED:
+                        raise
+                dv.free()
+                dh.free()
+                if dm:
+                    dm.free()
+            finally:
+                if b.qp_map is not None:
+                    b.qp_map.free()
+                b.free()
+        if case % 50 == 49:
+            print("soak: %d cases, %d mismatches" % (case + 1, bad), flush=True)
+    print("soak done: %d cases, %d mismatches" % (a.cases, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
