@@ -299,10 +299,10 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         }
     }
 
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 3) { /* 3 = the filter with the timing-only ablation switches compiled in */
         const dbk::BlockBs bs = load_bs_buffer<PATH != 0>(a, f, by, bx, active);
         const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
-        dbk::packed_filter_block<CHROMA>(L, R, bs, q, a.diag_ablate);
+        dbk::packed_filter_block<CHROMA>(L, R, bs, q, MODE == 3 ? a.diag_ablate : 0);
     } else if constexpr (MODE == 2) { /* spec-exact mode, H.265 8.7.2 */
         int entry[4];
         load_bs_buffer_h265<PATH>(a, f, by, bx, active, entry);
@@ -911,6 +911,8 @@ static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int
         else hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 512>), grid, block, 0, stream, a);
     } else if (mode == 1)
         hipLaunchKernelGGL((dbk_packed_kernel<false, 1, NT, LINEAR, false>), grid, block, 0, stream, a);
+    else if (mode == 0 && !chroma && !qm && a.diag_ablate) /* HEVCDBK_TUNE=nostrong|nonormal|barriers: wrong pixels, timing only */
+        hipLaunchKernelGGL((dbk_packed_kernel<false, 3, NT, LINEAR, false>), grid, block, 0, stream, a);
     else if (chroma) {
         if (qm) hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT, LINEAR, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT, LINEAR, false>), grid, block, 0, stream, a);
