@@ -368,7 +368,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
  * they are (no widening needed), so twice the bytes per pixel at the same instruction count: this is
  * the variant that runs into the HBM roof (BASELINE config 5).
  */
-template <int MODE, bool NT, bool EDGE, bool QPMAP, bool CHROMA = false>
+template <int MODE, bool NT, bool EDGE, bool QPMAP, bool CHROMA = false, bool WIDE = false>
 __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, int bx, bool active,
                                               const DbkH265Args *hx = nullptr) /* hx: MODE 2 (spec-exact) only */
 {
@@ -406,7 +406,7 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
         const dbk::BlockBs bs = load_bs_buffer<EDGE>(a, f, by, bx, active);
         const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
         if constexpr (CHROMA) dbk::packed_filter_chroma_block16(W, bs, q, a.max_v);
-        else dbk::packed_filter_luma_block16(W, bs, q, a.max_v);
+        else dbk::packed_filter_luma_block16<WIDE>(W, bs, q, a.max_v);
     } else if constexpr (MODE == 2) { /* spec-exact mode, H.265 8.7.2 */
         int entry[4];
         load_bs_buffer_h265<EDGE ? 2 : 0>(a, f, by, bx, active, entry);
@@ -513,13 +513,13 @@ __device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
     }
 }
 
-template <int MODE, bool NT, bool LINEAR, bool QPMAP>
+template <int MODE, bool NT, bool LINEAR, bool QPMAP, bool WIDE = false>
 __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
 {
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
-    if (c.interior) packed16_body<MODE, NT, false, QPMAP>(a, c.by, c.f, c.bx, true);
-    else packed16_body<MODE, NT, true, QPMAP>(a, c.by, c.f, c.bx, c.active);
+    if (c.interior) packed16_body<MODE, NT, false, QPMAP, false, WIDE>(a, c.by, c.f, c.bx, true);
+    else packed16_body<MODE, NT, true, QPMAP, false, WIDE>(a, c.by, c.f, c.bx, c.active);
 }
 
 /* 16-bit containers: reference-exact chroma, and the spec-exact mode's luma / chroma (deblock_packed16.h) */
@@ -869,10 +869,10 @@ bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
     /* the packed kernels address a plane through a buffer resource with 32-bit offsets */
     if ((unsigned long long)a.pitch * (unsigned long long)a.plane_h >= (1ull << 31)) return false;
     if (sample_bytes == 1) return a.max_v == 255;                /* 8-bit: luma and chroma */
-    /* 16-bit containers: luma, and only while every intermediate fits int16: the normal filter's
-     * 9*(q0-p0) - 3*(q1-p1) + 8 needs 12*max_v + 8 <= 32767, i.e. bit depth <= 11 */
-    /* chroma: 4*(p0-q0) + p1 - q1 + 4 needs 5*max_v + 4 <= 32767, i.e. bit depth <= 12 */
-    return a.max_v <= (chroma ? 4095 : 2047) && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
+    /* 16-bit containers up to 12 bit.  Luma: up to 11 bit every intermediate fits int16 (the normal filter's
+     * 9*(q0-p0) - 3*(q1-p1) + 8 needs 12*max_v + 8 <= 32767); 12 bit runs the WIDE variant of the core.
+     * Chroma: 4*(p0-q0) + p1 - q1 + 4 needs 5*max_v + 4 <= 32767 */
+    return a.max_v <= 4095 && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
            ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0;
 }
 
@@ -903,7 +903,10 @@ static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int
         else hipLaunchKernelGGL((dbk_packed16c_kernel<LINEAR, false>), grid, block, 0, stream, a);
     } else if (sample_bytes == 2) {
         if (mode == 1) hipLaunchKernelGGL((dbk_packed16_kernel<1, NT, LINEAR, false>), grid, block, 0, stream, a);
-        else if (qm) hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, true>), grid, block, 0, stream, a);
+        else if (a.max_v > 2047) { /* 12 bit: the WIDE variant of the core (deblock_packed.h) */
+            if (qm) hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, true, true>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, false, true>), grid, block, 0, stream, a);
+        } else if (qm) hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, false>), grid, block, 0, stream, a);
     } else if (mode == 0 && !chroma && !qm && a.use_queue && block.x <= 512) {
         if (block.x <= 128) hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 128>), grid, block, 0, stream, a);

@@ -179,12 +179,26 @@ DBK_HD Decision decide(const Taps &a, int beta, int tc)
 
 /* ---- filters on one line pair ------------------------------------------------------------------- */
 
+/* x >> N of fields that are non-negative but may exceed 2^15 (12-bit sums): 32-bit logical shift + field mask (two
+ * 2-cycle instructions; the packed arithmetic shift would read such a field as negative) */
+template <int N>
+DBK_HD pk lsr(pk x) { return bits_pk((pk_bits(x) >> N) & (0x00010001u * (0xffffu >> N))); }
+/* WIDE = bit depth 12 (max_v <= 4095): the strong filter's sums reach 38,908 and 9(q0-p0) - 3(q1-p1) + 8 reaches 49,148,
+ * both beyond int16; everything else still fits.  WIDE == false is the <= 11-bit code, unchanged. */
+template <bool WIDE, int N>
+DBK_HD pk shr_sum(pk x)
+{
+    if constexpr (WIDE) return lsr<N>(x);
+    else return x >> N;
+}
+
 /* strong filter (cpu.h:1152-1211), c = 2*tc.
  *
  * p' = clip(s, p - c, p + c) is evaluated as clip(s + c, p, p + 2c) - c: the "+ c" rides for free on the rounding
  * constants of the sums (s0 and s1 carry the shared p0+q0+2 term twice / once under >>3 / >>2, so that term takes
  * 2 + 4c; s2 gets the same constant once more), which removes the signed p - c of every tap and leaves max, min and
  * two carry-free 32-bit adds per output.  All fields stay non-negative and below 2^15 (8*max_v + 4 + 8c). */
+template <bool WIDE = false>
 DBK_HD void strong_pair(Taps &t, pk c)
 {
     const pk k = uaddc(uadd(uadd(c, c), uadd(c, c)), 0x00020002u); /* 2 + 4c */
@@ -195,12 +209,12 @@ DBK_HD void strong_pair(Taps &t, pk c)
     const pk bp = uadd(tp, t.p2);       /* p2+p1+p0+q0+2 (+4c) */
     const pk bq = uadd(tq, t.q2);
     const pk p32 = uadd(t.p3, t.p2), q32 = uadd(t.q3, t.q2);
-    const pk s0p = uadd(uadd(tp, bp), t.q1) >> 3;              /* (p2+2p1+2p0+2q0+q1+4)>>3  + c */
-    const pk s1p = bp >> 2;                                    /* (p2+p1+p0+q0+2)>>2        + c */
-    const pk s2p = uadd(uadd(uadd(p32, p32), bp), k) >> 3;     /* (2p3+3p2+p1+p0+q0+4)>>3   + c */
-    const pk s0q = uadd(uadd(tq, bq), t.p1) >> 3;
-    const pk s1q = bq >> 2;
-    const pk s2q = uadd(uadd(uadd(q32, q32), bq), k) >> 3;
+    const pk s0p = shr_sum<WIDE, 3>(uadd(uadd(tp, bp), t.q1));              /* (p2+2p1+2p0+2q0+q1+4)>>3  + c */
+    const pk s1p = shr_sum<WIDE, 2>(bp);                                    /* (p2+p1+p0+q0+2)>>2        + c */
+    const pk s2p = shr_sum<WIDE, 3>(uadd(uadd(uadd(p32, p32), bp), k));     /* (2p3+3p2+p1+p0+q0+4)>>3   + c */
+    const pk s0q = shr_sum<WIDE, 3>(uadd(uadd(tq, bq), t.p1));
+    const pk s1q = shr_sum<WIDE, 2>(bq);
+    const pk s2q = shr_sum<WIDE, 3>(uadd(uadd(uadd(q32, q32), bq), k));
     const pk np0 = usub(pk_min(pk_max(s0p, t.p0), uadd(t.p0, c2)), c);
     const pk np1 = usub(pk_min(pk_max(s1p, t.p1), uadd(t.p1, c2)), c);
     const pk np2 = usub(pk_min(pk_max(s2p, t.p2), uadd(t.p2, c2)), c);
@@ -213,12 +227,22 @@ DBK_HD void strong_pair(Taps &t, pk c)
 
 /* normal filter (cpu.h:1251-1354) up to, but not including, the final Clip2 to [0, max_v];
  * m5 / m6 = all-ones halves where cond5 / cond6 hold */
+template <bool WIDE = false>
 DBK_HD void normal_pair_unclipped(Taps &t, int tc, pk m5, pk m6)
 {
     const pk c = splat(2 * tc), c2 = splat(tc >> 1), lim = splat(10 * tc);
     const pk zero = splat(0);
     /* (9(q0-p0) - 3(q1-p1) + 8) >> 4 as two multiply-adds (v_pk_mad_i16) */
-    const pk delta = mad_k<9>(t.q0 - t.p0, mad_kc<-3, 8>(t.q1 - t.p1)) >> 4;
+    pk delta;
+    if constexpr (WIDE) {
+        /* 9a - 3b + 8 = 8a + r with r = a - 3b + 8 (|r| <= 16,388): (8a + r) >> 4 == (a + (r >> 3)) >> 1, floors included:
+         * r = 8t + rho, 0 <= rho < 8, adds rho/16 < 1/2 to (a + t)/2, which cannot reach the next integer */
+        const pk a = t.q0 - t.p0;
+        const pk r = mad_k<-3>(t.q1 - t.p1, a + splat(8));
+        delta = (a + (r >> 3)) >> 1;
+    } else {
+        delta = mad_k<9>(t.q0 - t.p0, mad_kc<-3, 8>(t.q1 - t.p1)) >> 4;
+    }
     const pk on = (pk_abs(delta) - lim) >> 15;       /* all ones where |delta| < 10*tc (cpu.h:1254) */
     const pk D = pk_clamp(delta, zero - c, c);
     /* (((p2+p0+1)>>1) - p1 + D) >> 1  ==  (p2 + p0 + 1 - 2*p1 + 2*D) >> 2   (floor of a floor: the dropped
@@ -238,10 +262,11 @@ DBK_HD void normal_pair_unclipped(Taps &t, int tc, pk m5, pk m6)
  * within 2*tc of 0 or max_v; one OR over the eight results shows whether any field left [0, max_v]
  * (a negative field has its top bits set, a too-large one has a bit above max_v), and the 16
  * min/max instructions run only in waves where some lane needs them. */
+template <bool WIDE = false>
 DBK_HD void normal_pairs(Taps &a, Taps &b, int tc, pk m5, pk m6, int max_v)
 {
-    normal_pair_unclipped(a, tc, m5, m6);
-    normal_pair_unclipped(b, tc, m5, m6);
+    normal_pair_unclipped<WIDE>(a, tc, m5, m6);
+    normal_pair_unclipped<WIDE>(b, tc, m5, m6);
     const uint32_t over = (pk_bits(a.p0) | pk_bits(a.q0) | pk_bits(a.p1) | pk_bits(a.q1) |
                            pk_bits(b.p0) | pk_bits(b.q0) | pk_bits(b.p1) | pk_bits(b.q1)) &
                           (0x00010001u * (0xffffu & ~(uint32_t)max_v));
@@ -257,17 +282,18 @@ DBK_HD void normal_pairs(Taps &a, Taps &b, int tc, pk m5, pk m6, int max_v)
 /* one luma segment given its two unpacked pairs; returns false when nothing changed */
 /* ablate (diagnostic builds of the benchmark only, 0 in the product): 1 = treat strong segments as
  * normal, 2 = skip the normal filter -- wrong pixels, used to price each path on the GPU */
+template <bool WIDE = false>
 DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc, int max_v = 255, int ablate = 0)
 {
     const Decision d = decide(a, beta, tc);
     if (!d.filter) return false;
     if (d.strong && ablate != 1) {
         const pk c = splat(2 * tc);
-        strong_pair(a, c);
-        strong_pair(b, c);
+        strong_pair<WIDE>(a, c);
+        strong_pair<WIDE>(b, c);
     } else if (ablate != 2) {
         const pk m5 = splat(d.cond5 ? -1 : 0), m6 = splat(d.cond6 ? -1 : 0);
-        normal_pairs(a, b, tc, m5, m6, max_v);
+        normal_pairs<WIDE>(a, b, tc, m5, m6, max_v);
     }
     return true;
 }
@@ -346,11 +372,12 @@ DBK_HD void diag_barriers(int ablate)
 /* the four segments on already-unpacked ver registers; leaves the final values in
  * ha/hb (cols 0..3 of rows 0..3 as P, taps p3..p0), ga/gb (P = cols 4..7 of rows 0..3, Q = cols 0..3 of
  * rows 4..7) and va2/vb2 q taps (cols 4..7 of rows 4..7) */
+template <bool WIDE = false>
 DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const BlockBs &bs, const BlockQp &q,
                             int max_v, Taps &ha, Taps &hb, Taps &ga, Taps &gb, int ablate = 0)
 {
-    if (bs.ver1 > 0) luma_pairs(va1, vb1, q.beta[0], q.tc[0], max_v, ablate); /* cpu.h:164 */
-    if (bs.ver2 > 0) luma_pairs(va2, vb2, q.beta[1], q.tc[1], max_v, ablate); /* cpu.h:228 */
+    if (bs.ver1 > 0) luma_pairs<WIDE>(va1, vb1, q.beta[0], q.tc[0], max_v, ablate); /* cpu.h:164 */
+    if (bs.ver2 > 0) luma_pairs<WIDE>(va2, vb2, q.beta[1], q.tc[1], max_v, ablate); /* cpu.h:228 */
     diag_barriers(ablate);
 
     /* hor1: lines = cols 0..3, pair A = cols (0,3) = ver taps (p3,p0), pair B = cols (1,2) = (p2,p1);
@@ -363,7 +390,7 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
     ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1); /* row 5 */
     ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1); /* row 6 */
     ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1); /* row 7 */
-    if (bs.hor1 > 0) luma_pairs(ha, hb, q.beta[2], q.tc[2], max_v, ablate); /* cpu.h:292 */
+    if (bs.hor1 > 0) luma_pairs<WIDE>(ha, hb, q.beta[2], q.tc[2], max_v, ablate); /* cpu.h:292 */
     diag_barriers(ablate);
 
     /* hor2: P lines = cols 4..7 (ver taps q0..q3) of rows 3..0, pair A = cols (4,7), B = cols (5,6);
@@ -374,7 +401,7 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
     ga.p3 = pick_lo(va1.q0, va1.q3); gb.p3 = pick_lo(va1.q1, va1.q2); /* row 0 */
     ga.q0 = ha.q0; ga.q1 = ha.q1; ga.q2 = ha.q2; ga.q3 = ha.q3;
     gb.q0 = hb.q0; gb.q1 = hb.q1; gb.q2 = hb.q2; gb.q3 = hb.q3;
-    if (bs.hor2 > 0) luma_pairs(ga, gb, q.beta[3], q.tc[3], max_v, ablate); /* cpu.h:373 */
+    if (bs.hor2 > 0) luma_pairs<WIDE>(ga, gb, q.beta[3], q.tc[3], max_v, ablate); /* cpu.h:373 */
     diag_barriers(ablate);
 }
 
@@ -415,12 +442,13 @@ DBK_HD Taps unpack_ver16(const uint32_t (&a)[4], const uint32_t (&b)[4])
     return t;
 }
 
+template <bool WIDE = false>
 DBK_HD void packed_filter_luma_block16(uint32_t (&W)[8][4], const BlockBs &bs, const BlockQp &q, int max_v)
 {
     Taps va1 = unpack_ver16(W[0], W[3]), vb1 = unpack_ver16(W[1], W[2]);
     Taps va2 = unpack_ver16(W[4], W[7]), vb2 = unpack_ver16(W[5], W[6]);
     Taps ha, hb, ga, gb;
-    luma_block_core(va1, vb1, va2, vb2, bs, q, max_v, ha, hb, ga, gb);
+    luma_block_core<WIDE>(va1, vb1, va2, vb2, bs, q, max_v, ha, hb, ga, gb);
 
     /* pair A = cols (0,3) / (4,7), pair B = cols (1,2) / (5,6):  (c0,c1) = (A.lo,B.lo), (c2,c3) = (B.hi,A.hi) */
 #define DBK_ROW16(r, A, B, j)                                 \

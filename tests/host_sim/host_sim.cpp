@@ -70,7 +70,8 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
                 uint32_t W[8][4];
                 for (int r = 0; r < 8; r++)
                     for (int j = 0; j < 4; j++) W[r][j] = (uint32_t)v[r][2 * j] | ((uint32_t)v[r][2 * j + 1] << 16);
-                dbk::packed_filter_luma_block16(W, bs, q, max_v);
+                if (max_v > 2047) dbk::packed_filter_luma_block16<true>(W, bs, q, max_v); /* 12 bit: wide sums */
+                else dbk::packed_filter_luma_block16(W, bs, q, max_v);
                 for (int r = 0; r < 8; r++)
                     for (int j = 0; j < 4; j++) {
                         v[r][2 * j] = W[r][j] & 0xffff;

@@ -161,13 +161,23 @@ def test_device_10bit_luma_and_chroma(ctx, oracle):
         t = synth.blocky_plane(size[0], size[1], seed=9, bit_depth=11)
         got = run_batch(ctx, t[None], 40, variant=_lib.KERNEL_PACKED, bit_depth=11)
         assert np.array_equal(got[0], oracle.filter_plane(t, 40, bit_depth=11)), size
-    # 12 bit and up: intermediates no longer fit int16 -> AUTO falls back to the generic 32-bit kernel, PACKED refuses
+    # 12 bit: the WIDE variant of the packed core (sums beyond int16); uniform noise, blocky content, saturated samples
     t = np.random.default_rng(5).integers(0, 4096, (64, 256), dtype=np.uint16)
-    got = run_batch(ctx, t[None], 51, variant=_lib.KERNEL_AUTO, bit_depth=12)
-    assert np.array_equal(got[0], oracle.filter_plane(t, 51, bit_depth=12))
+    t2 = synth.blocky_plane(1032, 72, seed=12, bit_depth=12).copy()
+    t2[40:, 512:] = 4095
+    t2[:16, :64] = 0
+    for plane in (t, t2):
+        for qp in (30, 42, 51):
+            for variant in (_lib.KERNEL_AUTO, _lib.KERNEL_PACKED, _lib.KERNEL_GENERIC):
+                got = run_batch(ctx, plane[None], qp, variant=variant, bit_depth=12)
+                assert np.array_equal(got[0], oracle.filter_plane(plane, qp, bit_depth=12)), (plane.shape, qp, variant)
+    # 13 bit and up: AUTO takes the 32-bit kernel, PACKED refuses
+    t = np.random.default_rng(6).integers(0, 8192, (64, 256), dtype=np.uint16)
+    got = run_batch(ctx, t[None], 51, variant=_lib.KERNEL_AUTO, bit_depth=13)
+    assert np.array_equal(got[0], oracle.filter_plane(t, 51, bit_depth=13))
     from gpu_video_codec_amd import deblock
     with pytest.raises(deblock.DeblockError) as e:
-        run_batch(ctx, t[None], 51, variant=_lib.KERNEL_PACKED, bit_depth=12)
+        run_batch(ctx, t[None], 51, variant=_lib.KERNEL_PACKED, bit_depth=13)
     assert e.value.code == _lib.ERR_UNSUPPORTED
     got = run_batch(ctx, y[None], 40, variant=_lib.KERNEL_AUTO, bit_depth=10, is_chroma=True)
     assert np.array_equal(got[0], oracle.filter_plane(y, 40, bit_depth=10, is_chroma=True))

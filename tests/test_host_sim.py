@@ -110,7 +110,7 @@ def test_packed_16bit_luma(sim, oracle, golden_inputs):
         pytest.skip("packed core not built")
     from gpu_video_codec_amd import synth
     rng = np.random.default_rng(21)
-    for bd in (10, 11):  # the packed core is exact while 12*max_v + 8 fits int16, i.e. up to 11 bit
+    for bd in (10, 11, 12):  # up to 11 bit every intermediate fits int16; 12 bit takes the WIDE variant of the core
         for (w, h) in [(8, 8), (64, 48), (520, 72)]:
             for qp in (22, 32, 45, 51):
                 y = synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30)), bit_depth=bd).copy()
