@@ -426,7 +426,7 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
                 sg.tc[i] = (entry[i] & dbk::kH265BsMask) == 2 ? hx->tc_bs2 : hx->tc_bs1;
             }
         }
-        dbk::packed_filter_block16_h265<CHROMA>(W, sg, a.max_v);
+        dbk::packed_filter_block16_h265<CHROMA, WIDE>(W, sg, a.max_v);
     }
 
     if constexpr (!EDGE) {
@@ -531,14 +531,14 @@ __global__ __launch_bounds__(1024) void dbk_packed16c_kernel(const DbkArgs a)
     if (c.interior) packed16_body<0, false, false, QPMAP, true>(a, c.by, c.f, c.bx, true);
     else packed16_body<0, false, true, QPMAP, true>(a, c.by, c.f, c.bx, c.active);
 }
-template <bool CHROMA, bool LINEAR, bool QPMAP>
+template <bool CHROMA, bool LINEAR, bool QPMAP, bool WIDE = false>
 __global__ __launch_bounds__(1024) void dbk_packed16_h265_kernel(const DbkH265Args h)
 {
     const DbkArgs &a = h.base;
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
-    if (c.interior) packed16_body<2, false, false, QPMAP, CHROMA>(a, c.by, c.f, c.bx, true, &h);
-    else packed16_body<2, false, true, QPMAP, CHROMA>(a, c.by, c.f, c.bx, c.active, &h);
+    if (c.interior) packed16_body<2, false, false, QPMAP, CHROMA, WIDE>(a, c.by, c.f, c.bx, true, &h);
+    else packed16_body<2, false, true, QPMAP, CHROMA, WIDE>(a, c.by, c.f, c.bx, c.active, &h);
 }
 
 /*
@@ -1020,8 +1020,9 @@ bool dbk_packed_h265_supports(const DbkH265Args &h, int sample_bytes, bool chrom
     const DbkArgs &a = h.base;
     if ((unsigned long long)a.pitch * (unsigned long long)a.plane_h >= (1ull << 31)) return false;
     if (sample_bytes == 1) return a.max_v == 255;
-    /* 16-bit containers: int16 intermediates hold up to 11 bit (luma) / 12 bit (chroma), see deblock_packed16.h */
-    return a.max_v <= (chroma ? 4095 : 2047) && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
+    /* 16-bit containers up to 12 bit (12-bit luma: the WIDE variant), see deblock_packed16.h */
+    (void)chroma;
+    return a.max_v <= 4095 && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
            ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0;
 }
 
@@ -1046,7 +1047,10 @@ hipError_t dbk_launch_packed_h265(const DbkH265Args &h, int sample_bytes, bool c
     }
 #define DBK_H265_LAUNCH(C, LIN)                                                                                       \
     do {                                                                                                              \
-        if (sample_bytes == 2) {                                                                                      \
+        if (sample_bytes == 2 && !C && g.base.max_v > 2047) { /* 12-bit luma */                                       \
+            if (g.base.qp_map) hipLaunchKernelGGL((dbk_packed16_h265_kernel<false, LIN, true, true>), grid, block, 0, stream, g); \
+            else hipLaunchKernelGGL((dbk_packed16_h265_kernel<false, LIN, false, true>), grid, block, 0, stream, g);  \
+        } else if (sample_bytes == 2) {                                                                               \
             if (g.base.qp_map) hipLaunchKernelGGL((dbk_packed16_h265_kernel<C, LIN, true>), grid, block, 0, stream, g); \
             else hipLaunchKernelGGL((dbk_packed16_h265_kernel<C, LIN, false>), grid, block, 0, stream, g);            \
         } else if (g.base.qp_map) hipLaunchKernelGGL((dbk_packed_h265_kernel<C, LIN, true>), grid, block, 0, stream, g); \

@@ -60,11 +60,18 @@ DBK_HD void strong_pair_h265(Taps &t, pk cp, pk cq)
 }
 
 /* normal filter, delta clipped to +-tc; mp0 / mq0 gate p0 / q0, mp1 / mq1 gate p1 / q1 (dEp, dEq and the keep flags) */
+template <bool WIDE = false>
 DBK_HD void normal_pair_h265(Taps &t, int tc, pk mp0, pk mq0, pk mp1, pk mq1)
 {
     const pk c = splat(tc), c2 = splat(tc >> 1), lim = splat(10 * tc);
     const pk zero = splat(0);
-    const pk delta = mad_k<9>(t.q0 - t.p0, mad_kc<-3, 8>(t.q1 - t.p1)) >> 4;
+    pk delta;
+    if constexpr (WIDE) { /* 12 bit: see normal_pair_unclipped<true> in deblock_packed.h */
+        const pk a = t.q0 - t.p0;
+        delta = (a + (mad_k<-3>(t.q1 - t.p1, a + splat(8)) >> 3)) >> 1;
+    } else {
+        delta = mad_k<9>(t.q0 - t.p0, mad_kc<-3, 8>(t.q1 - t.p1)) >> 4;
+    }
     const pk on = (pk_abs(delta) - lim) >> 15;
     const pk D = pk_clamp(delta, zero - c, c);
     const pk xp = uaddc(uadd(t.p2, t.p0), 0x00010001u);
@@ -79,6 +86,7 @@ DBK_HD void normal_pair_h265(Taps &t, int tc, pk mp0, pk mq0, pk mp1, pk mq1)
 }
 
 /* one luma segment from its two pairs; entry = bS byte with the keep flags; beta / tc already looked up */
+template <bool WIDE = false>
 DBK_HD void luma_pairs_h265(Taps &a, Taps &b, int entry, int beta, int tc, int max_v)
 {
     if ((entry & kH265BsMask) == 0) return;
@@ -92,8 +100,8 @@ DBK_HD void luma_pairs_h265(Taps &a, Taps &b, int entry, int beta, int tc, int m
     } else {
         const pk mp0 = splat(kp ? 0 : -1), mq0 = splat(kq ? 0 : -1);
         const pk mp1 = splat((d.cond5 && !kp) ? -1 : 0), mq1 = splat((d.cond6 && !kq) ? -1 : 0);
-        normal_pair_h265(a, tc, mp0, mq0, mp1, mq1);
-        normal_pair_h265(b, tc, mp0, mq0, mp1, mq1);
+        normal_pair_h265<WIDE>(a, tc, mp0, mq0, mp1, mq1);
+        normal_pair_h265<WIDE>(b, tc, mp0, mq0, mp1, mq1);
         const uint32_t over = (pk_bits(a.p0) | pk_bits(a.q0) | pk_bits(a.p1) | pk_bits(a.q1) |
                                pk_bits(b.p0) | pk_bits(b.q0) | pk_bits(b.p1) | pk_bits(b.q1)) &
                               (0x00010001u * (0xffffu & ~(uint32_t)max_v));

@@ -151,7 +151,11 @@ static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint
                     for (int j = 0; j < 4; j++) W[r][j] = (uint32_t)v[r][2 * j] | ((uint32_t)v[r][2 * j + 1] << 16);
                 dbk::H265Seg sg;
                 if (c_idx) { dbk::h265_seg_params<true>(entry, qpl, prm, sg); dbk::packed_filter_block16_h265<true>(W, sg, prm.max_v); }
-                else { dbk::h265_seg_params<false>(entry, qpl, prm, sg); dbk::packed_filter_block16_h265<false>(W, sg, prm.max_v); }
+                else {
+                    dbk::h265_seg_params<false>(entry, qpl, prm, sg);
+                    if (prm.max_v > 2047) dbk::packed_filter_block16_h265<false, true>(W, sg, prm.max_v);
+                    else dbk::packed_filter_block16_h265<false>(W, sg, prm.max_v);
+                }
                 for (int r = 0; r < 8; r++)
                     for (int j = 0; j < 4; j++) {
                         v[r][2 * j] = W[r][j] & 0xffff;

@@ -244,8 +244,8 @@ def test_kernel_block_arithmetic_equals_picture_order_oracle(h265, sim):
                     want = h265.filter_plane(plane, qp, vb, hb, c_idx=c_idx, bit_depth=bd, qp_map=qmap, unit_log2=3,
                                              tc_offset_div2=offs["tc_off"], beta_offset_div2=offs["beta_off"],
                                              c_qp_offset=offs["c_qp_off"])
-                    # 1 = the packed-int16 form the fast kernels run (luma up to 11 bit, chroma up to 12)
-                    for packed in ((0, 1) if (bd <= 11 or c_idx) else (0,)):
+                    # 1 = the packed-int16 form the fast kernels run (up to 12 bit)
+                    for packed in (0, 1):
                         got = sim_filter(sim, plane, qp, vb, hb, c_idx=c_idx, bit_depth=bd, qp_map=qmap, unit_log2=3,
                                          packed=packed, **offs)
                         assert np.array_equal(got, want), (w, h, bd, qp, c_idx, use_map, offs, packed)
