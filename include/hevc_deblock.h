@@ -116,6 +116,8 @@ typedef struct {
     double total_s; /* "Execution Time with copy on GPU"     : exec + copy      (gpu.cu:1302)      */
     double copy_s;  /* "Copy Operation Time with GPU buffers": H2D + D2H        (gpu.cu:1246-1258, 1294-1300) */
     double pipelined_s; /* wall time of the overlapped pinned/async pipeline actually run */
+    /* Small frames (<= 2 MiB) are not copied at all: the kernel reads and writes page-locked host memory across PCIe
+     * itself, so copy_s is 0 and exec_s contains the PCIe traffic.  Large frames: sums over the strips of the frame. */
 } hevcdbk_timing;
 
 /*

@@ -79,7 +79,8 @@ def test_config2_mother_daughter_full_file(ctx, oracle, golden_inputs):
     y, u, v = (p.copy() for p in oracle.split_yuv420(golden_inputs["mother-daughter"], 352, 288))
     t = ctx.filter_frame(y, u, v, qp=35)
     assert oracle.join_yuv420(y, u, v) == want
-    assert t["exec_s"] > 0 and t["copy_s"] > 0 and abs(t["total_s"] - t["exec_s"] - t["copy_s"]) < 1e-9
+    # small frames: the kernel reads and writes the page-locked staging buffer itself, so there is no copy phase
+    assert t["exec_s"] > 0 and t["copy_s"] >= 0 and abs(t["total_s"] - t["exec_s"] - t["copy_s"]) < 1e-9
 
 
 def test_golden_synth_4k_frame(ctx, oracle, manifest):
@@ -627,7 +628,11 @@ def test_single_frame_operator_on_page_locked_planes(ctx, oracle):
     """A large frame whose planes live in page-locked caller memory is DMA'd where it lies (no staging copy), pitched rows
     included; pinned and pageable planes may be mixed within one frame.  Results and untouched row padding as always."""
     from gpu_video_codec_amd import synth
-    w, h = 1920, 1088
+    for (w, h) in ((1920, 1088), (352, 288)):  # the strip pipeline, and the small-frame path (kernel on the planes themselves)
+        _page_locked_case(ctx, oracle, synth, w, h)
+
+
+def _page_locked_case(ctx, oracle, synth, w, h):
     y, u, v = synth.blocky_yuv420(w, h, seed=61)
     want = oracle.split_yuv420(oracle.filter_yuv420(oracle.join_yuv420(y, u, v), w, h, 33), w, h)
     for mix in ((True, True, True), (True, False, True), (False, True, False)):
