@@ -34,6 +34,10 @@ struct DbkArgs {
     int by_begin, by_count;
 };
 
+/* the next launch made from this host thread through any dbk_launch_* of deblock_kernels.hip records the kernel's own begin
+ * into `start` and its end into `stop` (either may be NULL); one-shot */
+void dbk_set_next_launch_events(hipEvent_t start, hipEvent_t stop);
+
 /* one lane per offset block, 32-bit arithmetic; every operand kind */
 hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, hipStream_t stream);
 /* packed int16 arithmetic kernels: scalar QP; 8-bit samples (luma or chroma) and 16-bit containers (luma) */

@@ -11,6 +11,7 @@
  * No MFMA: this is byte/int16 arithmetic on a streaming in-place filter; the bound is HBM.
  */
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +21,24 @@
 #include "deblock_packed.h"
 #include "deblock_packed_h265.h"
 #include "deblock_packed16.h"
+
+/*
+ * Every launch goes through hipExtLaunchKernelGGL so that a caller can ask for the NEXT launch to stamp its own start and
+ * stop into two events (the dispatch's begin / end timestamps -- what a profiler's kernel trace reports -- with no barrier
+ * packets around the kernel).  One-shot and per host thread; without a request the events are NULL = an ordinary launch.
+ */
+static thread_local hipEvent_t t_next_start = nullptr, t_next_stop = nullptr;
+void dbk_set_next_launch_events(hipEvent_t start, hipEvent_t stop)
+{
+    t_next_start = start;
+    t_next_stop = stop;
+}
+#define DBK_LAUNCH(kernel, grid, block, stream, ...)                                              \
+    do {                                                                                           \
+        hipEvent_t s_ = t_next_start, e_ = t_next_stop;                                            \
+        t_next_start = t_next_stop = nullptr;                                                      \
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, s_, e_, 0, __VA_ARGS__);             \
+    } while (0)
 
 namespace {
 
@@ -124,9 +143,9 @@ hipError_t launch_generic_t(const DbkArgs &a, hipStream_t stream)
     dim3 block(64, 4, 1);
     dim3 grid((a.nbx + 63) / 64, ((a.by_count ? a.by_count : a.nby) + 3) / 4, a.n_frames);
     if (a.qp_map)
-        hipLaunchKernelGGL((dbk_generic_kernel<T, CHROMA, true>), grid, block, 0, stream, a);
+        DBK_LAUNCH((dbk_generic_kernel<T, CHROMA, true>), grid, block, stream, a);
     else
-        hipLaunchKernelGGL((dbk_generic_kernel<T, CHROMA, false>), grid, block, 0, stream, a);
+        DBK_LAUNCH((dbk_generic_kernel<T, CHROMA, false>), grid, block, stream, a);
     return hipGetLastError();
 }
 
@@ -899,29 +918,29 @@ static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int
 {
     const bool qm = a.qp_map != nullptr;
     if (sample_bytes == 2 && chroma && mode == 0) {
-        if (qm) hipLaunchKernelGGL((dbk_packed16c_kernel<LINEAR, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((dbk_packed16c_kernel<LINEAR, false>), grid, block, 0, stream, a);
+        if (qm) DBK_LAUNCH((dbk_packed16c_kernel<LINEAR, true>), grid, block, stream, a);
+        else DBK_LAUNCH((dbk_packed16c_kernel<LINEAR, false>), grid, block, stream, a);
     } else if (sample_bytes == 2) {
-        if (mode == 1) hipLaunchKernelGGL((dbk_packed16_kernel<1, NT, LINEAR, false>), grid, block, 0, stream, a);
+        if (mode == 1) DBK_LAUNCH((dbk_packed16_kernel<1, NT, LINEAR, false>), grid, block, stream, a);
         else if (a.max_v > 2047) { /* 12 bit: the WIDE variant of the core (deblock_packed.h) */
-            if (qm) hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, true, true>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, false, true>), grid, block, 0, stream, a);
-        } else if (qm) hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((dbk_packed16_kernel<0, NT, LINEAR, false>), grid, block, 0, stream, a);
+            if (qm) DBK_LAUNCH((dbk_packed16_kernel<0, NT, LINEAR, true, true>), grid, block, stream, a);
+            else DBK_LAUNCH((dbk_packed16_kernel<0, NT, LINEAR, false, true>), grid, block, stream, a);
+        } else if (qm) DBK_LAUNCH((dbk_packed16_kernel<0, NT, LINEAR, true>), grid, block, stream, a);
+        else DBK_LAUNCH((dbk_packed16_kernel<0, NT, LINEAR, false>), grid, block, stream, a);
     } else if (mode == 0 && !chroma && !qm && a.use_queue && block.x <= 512) {
-        if (block.x <= 128) hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 128>), grid, block, 0, stream, a);
-        else if (block.x <= 256) hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 256>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((dbk_packed_q_kernel<NT, LINEAR, 512>), grid, block, 0, stream, a);
+        if (block.x <= 128) DBK_LAUNCH((dbk_packed_q_kernel<NT, LINEAR, 128>), grid, block, stream, a);
+        else if (block.x <= 256) DBK_LAUNCH((dbk_packed_q_kernel<NT, LINEAR, 256>), grid, block, stream, a);
+        else DBK_LAUNCH((dbk_packed_q_kernel<NT, LINEAR, 512>), grid, block, stream, a);
     } else if (mode == 1)
-        hipLaunchKernelGGL((dbk_packed_kernel<false, 1, NT, LINEAR, false>), grid, block, 0, stream, a);
+        DBK_LAUNCH((dbk_packed_kernel<false, 1, NT, LINEAR, false>), grid, block, stream, a);
     else if (mode == 0 && !chroma && !qm && a.diag_ablate) /* HEVCDBK_TUNE=nostrong|nonormal|barriers: wrong pixels, timing only */
-        hipLaunchKernelGGL((dbk_packed_kernel<false, 3, NT, LINEAR, false>), grid, block, 0, stream, a);
+        DBK_LAUNCH((dbk_packed_kernel<false, 3, NT, LINEAR, false>), grid, block, stream, a);
     else if (chroma) {
-        if (qm) hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT, LINEAR, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((dbk_packed_kernel<true, 0, NT, LINEAR, false>), grid, block, 0, stream, a);
+        if (qm) DBK_LAUNCH((dbk_packed_kernel<true, 0, NT, LINEAR, true>), grid, block, stream, a);
+        else DBK_LAUNCH((dbk_packed_kernel<true, 0, NT, LINEAR, false>), grid, block, stream, a);
     } else {
-        if (qm) hipLaunchKernelGGL((dbk_packed_kernel<false, 0, NT, LINEAR, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((dbk_packed_kernel<false, 0, NT, LINEAR, false>), grid, block, 0, stream, a);
+        if (qm) DBK_LAUNCH((dbk_packed_kernel<false, 0, NT, LINEAR, true>), grid, block, stream, a);
+        else DBK_LAUNCH((dbk_packed_kernel<false, 0, NT, LINEAR, false>), grid, block, stream, a);
     }
 }
 
@@ -1010,7 +1029,7 @@ hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t str
     const int per_wg = planes[0].nbx < cap ? planes[0].nbx : cap;
     dim3 block((per_wg + 63) / 64 * 64, 1, 1);
     dim3 grid(rows, planes[0].n_frames, (planes[0].nbx + (int)block.x - 1) / (int)block.x);
-    hipLaunchKernelGGL((dbk_packed_multi_kernel<false>), grid, block, 0, stream, m);
+    DBK_LAUNCH((dbk_packed_multi_kernel<false>), grid, block, stream, m);
     return hipGetLastError();
 }
 
@@ -1048,13 +1067,13 @@ hipError_t dbk_launch_packed_h265(const DbkH265Args &h, int sample_bytes, bool c
 #define DBK_H265_LAUNCH(C, LIN)                                                                                       \
     do {                                                                                                              \
         if (sample_bytes == 2 && !C && g.base.max_v > 2047) { /* 12-bit luma */                                       \
-            if (g.base.qp_map) hipLaunchKernelGGL((dbk_packed16_h265_kernel<false, LIN, true, true>), grid, block, 0, stream, g); \
-            else hipLaunchKernelGGL((dbk_packed16_h265_kernel<false, LIN, false, true>), grid, block, 0, stream, g);  \
+            if (g.base.qp_map) DBK_LAUNCH((dbk_packed16_h265_kernel<false, LIN, true, true>), grid, block, stream, g); \
+            else DBK_LAUNCH((dbk_packed16_h265_kernel<false, LIN, false, true>), grid, block, stream, g);  \
         } else if (sample_bytes == 2) {                                                                               \
-            if (g.base.qp_map) hipLaunchKernelGGL((dbk_packed16_h265_kernel<C, LIN, true>), grid, block, 0, stream, g); \
-            else hipLaunchKernelGGL((dbk_packed16_h265_kernel<C, LIN, false>), grid, block, 0, stream, g);            \
-        } else if (g.base.qp_map) hipLaunchKernelGGL((dbk_packed_h265_kernel<C, LIN, true>), grid, block, 0, stream, g); \
-        else hipLaunchKernelGGL((dbk_packed_h265_kernel<C, LIN, false>), grid, block, 0, stream, g);                  \
+            if (g.base.qp_map) DBK_LAUNCH((dbk_packed16_h265_kernel<C, LIN, true>), grid, block, stream, g); \
+            else DBK_LAUNCH((dbk_packed16_h265_kernel<C, LIN, false>), grid, block, stream, g);            \
+        } else if (g.base.qp_map) DBK_LAUNCH((dbk_packed_h265_kernel<C, LIN, true>), grid, block, stream, g); \
+        else DBK_LAUNCH((dbk_packed_h265_kernel<C, LIN, false>), grid, block, stream, g);                  \
     } while (0)
     if (linear) {
         if (chroma) DBK_H265_LAUNCH(true, true);
