@@ -127,7 +127,8 @@ def main():
                     help="untimed launches before the warm-up steps: under this VALU-heavy kernel the clock governor "
                          "dips for launches ~6-60 and then recovers (profiles/r01/clock_trace_*.txt); 100 launches "
                          "(~25 ms) put the timed region in the steady state instead of in that transient")
-    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=256,
+                    help="frames per GPU per step (one launch filters the whole batch; 256 x 4K 8-bit = 2.1 GB in + 2.1 GB out of 288 GB)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bit-depth", type=int, default=8)

@@ -21,7 +21,7 @@ run_stats() { # name, then the python script and its arguments
 }
 
 run_stats bench_default_1gpu "$R/bench.py"
-run_stats bench_8k10_1gpu "$R/bench.py" --width 7680 --height 4320 --bit-depth 10 --frames 12
+run_stats bench_8k10_1gpu "$R/bench.py" --width 7680 --height 4320 --bit-depth 10 --frames 48
 run_stats bench_h265 "$R/tools/bench_h265.py"
 run_stats e2e_small "$R/tools/e2e_small.py" --file-frames 300 --sequence-frames 256
 run_stats bench_yuv420 "$R/tools/bench_yuv420.py"
@@ -39,7 +39,7 @@ json.dump(res, open(out + "/kernel_trace_phases_packed_bench.json", "w"), indent
 print(json.dumps(res))
 PY
 python3 "$R/tools/hbm_traffic.py" --tag "$TAG" > "$OUT/hbm_traffic.log" 2>&1
-python3 "$R/tools/hbm_traffic.py" --tag "${TAG}_8k10" --width 7680 --height 4320 --bit-depth 10 --frames 12 >> "$OUT/hbm_traffic.log" 2>&1
+python3 "$R/tools/hbm_traffic.py" --tag "${TAG}_8k10" --width 7680 --height 4320 --bit-depth 10 --frames 48 >> "$OUT/hbm_traffic.log" 2>&1
 cp "$R"/gpurun_out/traffic/*_hbm_traffic.json "$OUT/" 2>/dev/null || true
 rm -rf "$OUT"/bench_default_1gpu "$OUT"/bench_8k10_1gpu "$OUT"/bench_h265 "$OUT"/e2e_small "$OUT"/bench_yuv420 "$OUT"/bench_sao "$OUT"/kernel_trace_*.csv
 ls -la "$OUT"

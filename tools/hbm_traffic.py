@@ -46,7 +46,7 @@ def run_pmc(counter, variant, frames, outdir, steps=3, extra=()):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="r01")
-    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bit-depth", type=int, default=8)

@@ -19,7 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variant", default="packed")
     ap.add_argument("--tag", default=None)
-    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=256)
     args, extra = ap.parse_known_args()
     tag = args.tag or args.variant
     outdir = os.path.join(ROOT, "gpurun_out", "sq")
