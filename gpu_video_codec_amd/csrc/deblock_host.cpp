@@ -763,7 +763,7 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
 
 namespace {
 int filter_chunk(hevcdbk_context *ctx, uint8_t *host, size_t k, unsigned W, unsigned H, unsigned qp, const hevcdbk_bs *bs,
-                 const hevcdbk_tables *tables);
+                 const hevcdbk_tables *tables, int slot = 0, hipEvent_t done = nullptr);
 }
 
 
@@ -796,24 +796,41 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
         if (chroma && sb == 1 && f0.bit_depth == 8 && fb <= ((size_t)2 << 20) && n_frames >= 4) {
             size_t G = ((size_t)64 << 20) / fb;
             G = G > 64 ? 64 : G;
-            if (int rc = grow_pinned(ctx, ctx->seq_pin[0][0], G * fb)) return rc;
-            uint8_t *chunk = (uint8_t *)ctx->seq_pin[0][0].p;
+            /* two pinned chunks, two device chunks: the GPU works on group g while the host un-stages group g-1 and stages g+1 */
+            uint8_t *chunk[2];
+            for (int c = 0; c < 2; c++) {
+                if (int rc = grow_pinned(ctx, ctx->seq_pin[0][c], G * fb)) return rc;
+                chunk[c] = (uint8_t *)ctx->seq_pin[0][c].p;
+                if (!ctx->seq_ev[0][c]) HIP_TRY(ctx, hipEventCreate(&ctx->seq_ev[0][c]));
+            }
             const size_t poff[3] = {0, (size_t)W * H, (size_t)W * H + (size_t)(W / 2) * (H / 2)};
             const auto wall0 = std::chrono::steady_clock::now();
-            for (unsigned g0 = 0; g0 < n_frames; g0 += (unsigned)G) {
+            auto stage = [&](unsigned g0, size_t k, uint8_t *c, bool in) {
+                for (size_t i = 0; i < k; i++)
+                    for (int p = 0; p < 3; p++)
+                        for (unsigned r = 0; r < ph[p]; r++) {
+                            uint8_t *cp = c + i * fb + poff[p] + (size_t)r * pw[p];
+                            uint8_t *fp = (uint8_t *)frames[g0 + i].plane[p] + r * frames[g0 + i].pitch[p];
+                            if (in) std::memcpy(cp, fp, pw[p]);
+                            else std::memcpy(fp, cp, pw[p]);
+                        }
+            };
+            unsigned prev_g0 = 0;
+            size_t prev_k = 0;
+            int n = 0;
+            for (unsigned g0 = 0; g0 < n_frames; g0 += (unsigned)G, n++) {
                 const size_t k = n_frames - g0 < G ? n_frames - g0 : G;
-                for (size_t i = 0; i < k; i++)
-                    for (int p = 0; p < 3; p++)
-                        for (unsigned r = 0; r < ph[p]; r++)
-                            std::memcpy(chunk + i * fb + poff[p] + (size_t)r * pw[p],
-                                        (const uint8_t *)frames[g0 + i].plane[p] + r * frames[g0 + i].pitch[p], pw[p]);
-                if (int rc = filter_chunk(ctx, chunk, k, W, H, qp->qp, bs, tables)) return rc;
-                for (size_t i = 0; i < k; i++)
-                    for (int p = 0; p < 3; p++)
-                        for (unsigned r = 0; r < ph[p]; r++)
-                            std::memcpy((uint8_t *)frames[g0 + i].plane[p] + r * frames[g0 + i].pitch[p],
-                                        chunk + i * fb + poff[p] + (size_t)r * pw[p], pw[p]);
+                stage(g0, k, chunk[n & 1], true);
+                if (int rc = filter_chunk(ctx, chunk[n & 1], k, W, H, qp->qp, bs, tables, n & 1, ctx->seq_ev[0][n & 1])) return rc;
+                if (prev_k) {
+                    HIP_TRY(ctx, hipEventSynchronize(ctx->seq_ev[0][(n - 1) & 1]));
+                    stage(prev_g0, prev_k, chunk[(n - 1) & 1], false);
+                }
+                prev_g0 = g0;
+                prev_k = k;
             }
+            HIP_TRY(ctx, hipEventSynchronize(ctx->seq_ev[0][(n - 1) & 1]));
+            stage(prev_g0, prev_k, chunk[(n - 1) & 1], false);
             if (timing) {
                 std::memset(timing, 0, sizeof(*timing));
                 timing->pipelined_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
@@ -1129,15 +1146,18 @@ int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p,
 namespace {
 
 /* k planar 8-bit 4:2:0 frames back to back in pinned host memory: upload, filter all planes as batches, download */
+/* slot: which of the two device chunk buffers to use; done == NULL: return when the chunk is back in `host`, else return at
+ * once and record `done` behind the download */
 int filter_chunk(hevcdbk_context *ctx, uint8_t *host, size_t k, unsigned W, unsigned H, unsigned qp, const hevcdbk_bs *bs,
-                 const hevcdbk_tables *tables)
+                 const hevcdbk_tables *tables, int slot, hipEvent_t done)
 {
     const size_t ysz = (size_t)W * H, csz = ysz / 4, fb = ysz + 2 * csz;
     const size_t nv = hevcdbk_num_vert_bs(W, H), nh = hevcdbk_num_hor_bs(W, H);
     const size_t ncv = hevcdbk_num_vert_bs(W / 2, H / 2);
     if (int rc = check_bs(bs, W, H, true)) return rc;
-    if (int rc = grow_device(ctx, ctx->dev[1], k * fb)) return rc;
-    uint8_t *d = (uint8_t *)ctx->dev[1].p;
+    Growable &dbuf = ctx->dev[1 + (slot & 1)];
+    if (int rc = grow_device(ctx, dbuf, k * fb)) return rc;
+    uint8_t *d = (uint8_t *)dbuf.p;
     hipStream_t s = ctx->compute;
     if (int rc = stage_bs(ctx, W, H, true, bs, s)) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d, host, k * fb, hipMemcpyHostToDevice, s));
@@ -1160,7 +1180,8 @@ int filter_chunk(hevcdbk_context *ctx, uint8_t *host, size_t k, unsigned W, unsi
         for (int i = 0; i < 3; i++)
             if (int rc = launch(ctx, args[i], 1, i != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(host, d, k * fb, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (done) HIP_TRY(ctx, hipEventRecord(done, s));
+    else HIP_TRY(ctx, hipStreamSynchronize(s));
     return HEVCDBK_OK;
 }
 
