@@ -10,7 +10,7 @@
 
 #include "../../include/hevc_deblock.h"
 
-void ExecuteGpu(std::string const &input_file_name, std::string const &output_file_name,
+HEVCDBK_API void ExecuteGpu(std::string const &input_file_name, std::string const &output_file_name,
                 unsigned int width, unsigned int height, unsigned int Qp,
                 unsigned dimx1, unsigned int dimy1, unsigned dimx2, unsigned int dimy2)
 {

@@ -26,6 +26,13 @@
 extern "C" {
 #endif
 
+/* the library is built with hidden visibility: only the entry points below leave it */
+#if defined(__GNUC__) || defined(__clang__)
+#define HEVCDBK_API __attribute__((visibility("default")))
+#else
+#define HEVCDBK_API
+#endif
+
 /* ---- error codes: the reference throws `const char *` at three sites; the ABI returns ---- */
 #define HEVCDBK_OK               0
 #define HEVCDBK_ERR_FILE_SIZE   (-1) /* cpu.h:43-45  / gpu.cu:1082-1084 "Incorrect file size" */
@@ -37,17 +44,17 @@ extern "C" {
 #define HEVCDBK_ERR_IO          (-7)
 #define HEVCDBK_ERR_UNSUPPORTED (-8) /* alignment / bit depth outside what the kernels handle */
 
-const char *hevcdbk_strerror(int code);
+HEVCDBK_API const char *hevcdbk_strerror(int code);
 
 /* ---- context: replaces the file-scope globals of gpu.cu:37-77 (one per device, re-entrant) ---- */
 typedef struct hevcdbk_context hevcdbk_context;
 
-int hevcdbk_device_count(void);
+HEVCDBK_API int hevcdbk_device_count(void);
 /* binds to HIP device `device`, creates the compute stream and the two copy side streams */
-int hevcdbk_create(int device, hevcdbk_context **ctx);
-void hevcdbk_destroy(hevcdbk_context *ctx);
+HEVCDBK_API int hevcdbk_create(int device, hevcdbk_context **ctx);
+HEVCDBK_API void hevcdbk_destroy(hevcdbk_context *ctx);
 /* text of the last HIP failure seen by this context ("" if none) */
-const char *hevcdbk_last_error(const hevcdbk_context *ctx);
+HEVCDBK_API const char *hevcdbk_last_error(const hevcdbk_context *ctx);
 /* GetGpuDeviceInfo() equivalent (main.cu:92-107): fills name, CU count, memory */
 typedef struct {
     char name[256];
@@ -59,17 +66,17 @@ typedef struct {
     size_t shared_mem_per_block;
     size_t total_const_mem;
 } hevcdbk_device_info;
-int hevcdbk_get_device_info(const hevcdbk_context *ctx, hevcdbk_device_info *info);
+HEVCDBK_API int hevcdbk_get_device_info(const hevcdbk_context *ctx, hevcdbk_device_info *info);
 
 /* ---- tables and bS helpers ---- */
 /* cpu.h:1021-1033 (copies at gpu.cu:80-85, 92-97) */
-const unsigned *hevcdbk_default_tc_table(void);   /* 52 entries */
-const unsigned *hevcdbk_default_beta_table(void); /* 52 entries */
+HEVCDBK_API const unsigned *hevcdbk_default_tc_table(void);   /* 52 entries */
+HEVCDBK_API const unsigned *hevcdbk_default_beta_table(void); /* 52 entries */
 /* cpu.h:86-87 / 104-105: element counts of the bS arrays of a plane_w x plane_h plane */
-size_t hevcdbk_num_vert_bs(unsigned plane_w, unsigned plane_h);
-size_t hevcdbk_num_hor_bs(unsigned plane_w, unsigned plane_h);
+HEVCDBK_API size_t hevcdbk_num_vert_bs(unsigned plane_w, unsigned plane_h);
+HEVCDBK_API size_t hevcdbk_num_hor_bs(unsigned plane_w, unsigned plane_h);
 /* cpu.h:92-99 / 110-117 (gpu.cu:1136-1180): the default "all intra" pattern, quirks included */
-int hevcdbk_default_bs(unsigned plane_w, unsigned plane_h, uint8_t *vert_bs, uint8_t *hor_bs);
+HEVCDBK_API int hevcdbk_default_bs(unsigned plane_w, unsigned plane_h, uint8_t *vert_bs, uint8_t *hor_bs);
 
 /* ---- operands of hevc_deblocking_filter(frame, bS, QP, tc/beta tables) ---- */
 
@@ -127,7 +134,7 @@ typedef struct {
  * side streams; planes of a large frame that already lie in page-locked memory
  * (hevcdbk_host_malloc_pinned) are DMA'd where they lie instead.  bs / tables / timing may be NULL.
  */
-int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_bs *bs,
+HEVCDBK_API int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_bs *bs,
                            const hevcdbk_qp *qp, const hevcdbk_tables *tables,
                            hevcdbk_timing *timing);
 
@@ -141,7 +148,7 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
  * 8-bit 4:2:0 frames (<= 2 MiB per frame, at least 4 of them) travel in groups of up to 64 frames instead: packed back to
  * back into one pinned chunk, one DMA each way and one batched launch per group.
  */
-int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_frame *frames, unsigned n_frames,
+HEVCDBK_API int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_frame *frames, unsigned n_frames,
                                     const hevcdbk_bs *bs, const hevcdbk_qp *qp, const hevcdbk_tables *tables,
                                     hevcdbk_timing *timing);
 
@@ -175,26 +182,26 @@ typedef struct {
 #define HEVCDBK_KERNEL_DIAG_COPY 100 /* diagnostic: the packed kernel's loads and stores with no arithmetic (dst = src);
                                        measures the memory-path ceiling of the access pattern, not a filter */
 
-int hevc_deblocking_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes,
+HEVCDBK_API int hevc_deblocking_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes,
                                   unsigned qp, const hevcdbk_tables *tables, int kernel_variant,
                                   void *hip_stream /* NULL => the context's compute stream */);
 
 /* ---- device memory / stream plumbing for hosts without a HIP binding (ctypes, cgo, JNI) ---- */
-int hevcdbk_device_malloc(hevcdbk_context *ctx, size_t bytes, void **dptr);
-int hevcdbk_device_free(hevcdbk_context *ctx, void *dptr);
-int hevcdbk_host_malloc_pinned(hevcdbk_context *ctx, size_t bytes, void **hptr); /* hipHostMalloc, replaces cudaMallocHost gpu.cu:1103-1169 */
-int hevcdbk_host_free_pinned(hevcdbk_context *ctx, void *hptr);
-int hevcdbk_memcpy_h2d(hevcdbk_context *ctx, void *dptr, const void *hptr, size_t bytes); /* synchronous */
-int hevcdbk_memcpy_d2h(hevcdbk_context *ctx, void *hptr, const void *dptr, size_t bytes);
-int hevcdbk_memcpy_d2d(hevcdbk_context *ctx, void *dst, const void *src, size_t bytes);
-int hevcdbk_memset_d(hevcdbk_context *ctx, void *dptr, int value, size_t bytes);
-int hevcdbk_synchronize(hevcdbk_context *ctx); /* all three streams */
-void *hevcdbk_compute_stream(hevcdbk_context *ctx); /* hipStream_t */
+HEVCDBK_API int hevcdbk_device_malloc(hevcdbk_context *ctx, size_t bytes, void **dptr);
+HEVCDBK_API int hevcdbk_device_free(hevcdbk_context *ctx, void *dptr);
+HEVCDBK_API int hevcdbk_host_malloc_pinned(hevcdbk_context *ctx, size_t bytes, void **hptr); /* hipHostMalloc, replaces cudaMallocHost gpu.cu:1103-1169 */
+HEVCDBK_API int hevcdbk_host_free_pinned(hevcdbk_context *ctx, void *hptr);
+HEVCDBK_API int hevcdbk_memcpy_h2d(hevcdbk_context *ctx, void *dptr, const void *hptr, size_t bytes); /* synchronous */
+HEVCDBK_API int hevcdbk_memcpy_d2h(hevcdbk_context *ctx, void *hptr, const void *dptr, size_t bytes);
+HEVCDBK_API int hevcdbk_memcpy_d2d(hevcdbk_context *ctx, void *dst, const void *src, size_t bytes);
+HEVCDBK_API int hevcdbk_memset_d(hevcdbk_context *ctx, void *dptr, int value, size_t bytes);
+HEVCDBK_API int hevcdbk_synchronize(hevcdbk_context *ctx); /* all three streams */
+HEVCDBK_API void *hevcdbk_compute_stream(hevcdbk_context *ctx); /* hipStream_t */
 
 /* Timed replay for benchmarks: launches the device operator `steps` times back-to-back on the
  * compute stream with a HIP event pair around EACH launch, synchronises once at the end and
  * writes the per-launch kernel durations (milliseconds) to kernel_ms[steps]. */
-int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
+HEVCDBK_API int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
                              unsigned qp, const hevcdbk_tables *tables, int kernel_variant,
                              unsigned steps, float *kernel_ms);
 
@@ -202,7 +209,7 @@ int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *
  * file in -> filter Y,U,V on the GPU -> file out, printing the reference's three lines.
  * The four launch-dimension arguments are accepted and ignored.  Returns an error code instead of
  * throwing.  `device` selects the HIP device (the reference always uses device 0, main.cu:93). */
-int hevcdbk_execute_gpu(const char *input_file_name, const char *output_file_name,
+HEVCDBK_API int hevcdbk_execute_gpu(const char *input_file_name, const char *output_file_name,
                         unsigned width, unsigned height, unsigned qp,
                         unsigned dimx1, unsigned dimy1, unsigned dimx2, unsigned dimy2, int device);
 
@@ -216,7 +223,7 @@ int hevcdbk_execute_gpu(const char *input_file_name, const char *output_file_nam
  * one file frame -- one fused Y+U+V launch per chunk when the geometry allows.  `bs` / `tables` as for hevc_deblocking_filter (NULL = the
  * reference's defaults).  in == out is refused.  timing->pipelined_s = wall time including file I/O.
  */
-int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *input_file_name, const char *output_file_name,
+HEVCDBK_API int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *input_file_name, const char *output_file_name,
                             unsigned width, unsigned height, unsigned qp, const hevcdbk_bs *bs,
                             const hevcdbk_tables *tables, unsigned *n_frames, hevcdbk_timing *timing);
 
@@ -227,7 +234,7 @@ int hevcdbk_filter_yuv_file(hevcdbk_context *ctx, const char *input_file_name, c
  * context.  A device may be listed more than once (two workers sharing one GPU).  The output is byte-identical to
  * hevcdbk_filter_yuv_file's.  Error codes as there; the first failing worker's code is returned.
  */
-int hevcdbk_filter_yuv_file_multi(const int *devices, unsigned n_devices, const char *input_file_name,
+HEVCDBK_API int hevcdbk_filter_yuv_file_multi(const int *devices, unsigned n_devices, const char *input_file_name,
                                   const char *output_file_name, unsigned width, unsigned height, unsigned qp,
                                   const hevcdbk_bs *bs, const hevcdbk_tables *tables, unsigned *n_frames,
                                   hevcdbk_timing *timing);
@@ -262,8 +269,8 @@ typedef struct hevcdbk_h265_params {
     int cr_qp_offset;     /* pps_cr_qp_offset */
 } hevcdbk_h265_params;
 
-size_t hevcdbk_h265_num_vert_bs(unsigned plane_w, unsigned plane_h); /* (plane_w/8+1) * (plane_h/4) */
-size_t hevcdbk_h265_num_hor_bs(unsigned plane_w, unsigned plane_h);  /* (plane_h/8+1) * (plane_w/4) */
+HEVCDBK_API size_t hevcdbk_h265_num_vert_bs(unsigned plane_w, unsigned plane_h); /* (plane_w/8+1) * (plane_h/4) */
+HEVCDBK_API size_t hevcdbk_h265_num_hor_bs(unsigned plane_w, unsigned plane_h);  /* (plane_h/8+1) * (plane_w/4) */
 
 /* per 4x4 luma unit prediction data the bS derivation (8.7.2.4) reads; (W/4) x (H/4) entries, row-major */
 #define HEVCDBK_U_INTRA     0x0001u /* CuPredMode == MODE_INTRA */
@@ -293,7 +300,7 @@ typedef struct hevcdbk_h265_units {
  * (w/2) x (h/2) plane: the luma entry at twice the chroma position (8.7.2.5).  Asynchronous on `hip_stream`
  * (NULL = the context's compute stream).
  */
-int hevcdbk_h265_derive_bs_device(hevcdbk_context *ctx, const hevcdbk_h265_units *units, unsigned width, unsigned height,
+HEVCDBK_API int hevcdbk_h265_derive_bs_device(hevcdbk_context *ctx, const hevcdbk_h265_units *units, unsigned width, unsigned height,
                                   uint8_t *vert_bs4, uint8_t *hor_bs4, uint8_t *chroma_vert_bs4, uint8_t *chroma_hor_bs4,
                                   void *hip_stream);
 
@@ -305,7 +312,7 @@ int hevcdbk_h265_derive_bs_device(hevcdbk_context *ctx, const hevcdbk_h265_units
  * entries); tc index = qPL + 2*(bS-1) + 2*tc_offset_div2, beta index = qPL + 2*beta_offset_div2, chroma through Table 8-10.
  * kernel_variant: HEVCDBK_KERNEL_AUTO, _GENERIC (32-bit arithmetic, every operand kind) or _PACKED (8-bit samples).
  */
-int hevc_deblocking_filter_h265_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, int c_idx, unsigned qp,
+HEVCDBK_API int hevc_deblocking_filter_h265_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, int c_idx, unsigned qp,
                                        const hevcdbk_h265_params *params, int kernel_variant, void *hip_stream);
 
 /*
@@ -314,7 +321,7 @@ int hevc_deblocking_filter_h265_device(hevcdbk_context *ctx, const hevcdbk_devic
  * chroma arrays are gathered from them on the GPU; its chroma_* members are ignored), filters Y and, when present, Cb and
  * Cr in place, downloads.  Exactly one of `units` / `bs4` must be non-NULL.  `qp` as for hevc_deblocking_filter.
  */
-int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_h265_units *units,
+HEVCDBK_API int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_h265_units *units,
                                 const hevcdbk_bs *bs4, const hevcdbk_qp *qp, const hevcdbk_h265_params *params,
                                 hevcdbk_timing *timing);
 
@@ -337,7 +344,7 @@ typedef struct hevcdbk_sao_ctb {
  * unmodified (PCM with pcm_loop_filter_disabled_flag, cu_transquant_bypass_flag), row stride keep_stride, frame stride
  * keep_frame_stride bytes.  Edge offset leaves a sample alone when one of its two neighbours is outside the picture.
  */
-int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, const hevcdbk_sao_ctb *params,
+HEVCDBK_API int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, const hevcdbk_sao_ctb *params,
                            unsigned params_stride, size_t params_frame_stride, unsigned ctb_log2, const uint8_t *keep,
                            unsigned keep_stride, size_t keep_frame_stride, void *hip_stream);
 

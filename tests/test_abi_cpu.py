@@ -168,3 +168,15 @@ def test_cpp_class_mirror_compiles_and_keeps_the_reference_errors(L, tmp_path):
     odd.write_bytes(b"\0" * (12 * 8 * 3 // 2))
     r = subprocess.run([exe, str(odd), out, "12", "8", "30"], capture_output=True, text=True)
     assert r.returncode == 1 and "multiplier of sample block size" in r.stderr
+
+
+def test_only_the_api_leaves_the_library():
+    """Built with hidden visibility: the dynamic symbol table holds the declared entry points, the C++ ExecuteGpu symbol and
+    nothing of the internal launch interface (generic names such as filter_chunk must not be interposable)."""
+    import subprocess
+    from gpu_video_codec_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode().split("\n")
+    names = [l.split()[-1] for l in out if l.strip()]
+    internal = [n for n in names if n.startswith("dbk_") or n in ("filter_chunk", "h265_args", "launch_h265") or "dbk_launch" in n]
+    assert not internal, internal
+    assert set(_lib.EXPORTS) <= set(names)
