@@ -1,0 +1,57 @@
+/*
+ * deblock_ctx.h -- PRIVATE to the library: the context behind `hevcdbk_context *` and the host-side helpers the C-ABI
+ * translation units share (deblock_host.cpp: context, plumbing, reference-exact operators, file operators;
+ * deblock_host_h265.cpp: spec-exact mode and SAO).  Nothing here is exported (the library is built with hidden visibility).
+ */
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/hevc_deblock.h"
+#include "deblock_kernels.h"
+
+struct Growable {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct hevcdbk_context {
+    int device = 0;
+    hipStream_t compute = nullptr, h2d = nullptr, d2h = nullptr;
+    hipEvent_t ev[16] = {};
+    std::string last_error;
+    /* staging for the host-frame operator: pinned host + device, grown on demand */
+    Growable pin[3], dev[3];
+    Growable pin_bs, dev_bs, dev_map, dev_units;
+    std::vector<hipEvent_t> timed_events;
+    /* streaming operator: ring of kSeqSlots frames in flight */
+    static constexpr int kSeqSlots = 3;
+    Growable seq_pin[kSeqSlots][3], seq_dev[kSeqSlots][3];
+    hipEvent_t seq_ev[kSeqSlots][3] = {}; /* [slot][0 = h2d done, 1 = kernels done, 2 = d2h done] */
+    /* dev_bs holds the DEFAULT bS (cpu.h:92-99) of this geometry when bs_default_at == dev_bs.p: no re-upload */
+    const void *bs_default_at = nullptr;
+    unsigned bs_default_w = 0, bs_default_h = 0;
+    bool bs_default_chroma = false;
+};
+
+namespace dbkh {
+
+bool hip_ok(hevcdbk_context *ctx, hipError_t e, const char *what);
+#define HIP_TRY(ctx, call)                                  \
+    do {                                                    \
+        if (!hip_ok((ctx), (call), #call)) return HEVCDBK_ERR_HIP; \
+    } while (0)
+
+int bind(hevcdbk_context *ctx);                                             /* hipSetDevice(ctx->device) */
+int grow_pinned(hevcdbk_context *ctx, Growable &g, size_t bytes);
+int grow_device(hevcdbk_context *ctx, Growable &g, size_t bytes);
+bool bad_depth(unsigned bit_depth, unsigned sample_bytes);
+bool is_pinned_host(const void *p);
+int check_frame(const hevcdbk_frame &f, bool &chroma);
+int check_bs(const hevcdbk_bs *bs, unsigned W, unsigned H, bool chroma);
+int planes_to_args(const hevcdbk_device_planes *p, unsigned qp, const hevcdbk_tables *tables, DbkArgs &a);
+int launch(hevcdbk_context *ctx, const DbkArgs &a, int sample_bytes, bool chroma, int variant, hipStream_t s);
+
+} /* namespace dbkh */

@@ -1,0 +1,232 @@
+/*
+ * deblock_host_h265.cpp -- C-ABI entries of the spec-exact mode (ITU-T H.265 clause 8.7.2: bS derivation, block filter,
+ * host-frame operator) and of sample adaptive offset (clause 8.7.3).  Context and shared helpers: deblock_ctx.h.
+ */
+#include <chrono>
+#include <cstring>
+
+#include "deblock_ctx.h"
+
+using namespace dbkh;
+
+extern "C" {
+
+/* ---- spec-exact mode (H.265 clause 8.7.2) ------------------------------------------------------------------ */
+
+size_t hevcdbk_h265_num_vert_bs(unsigned w, unsigned h) { return (size_t)(w / 8 + 1) * (h / 4); }
+size_t hevcdbk_h265_num_hor_bs(unsigned w, unsigned h) { return (size_t)(h / 8 + 1) * (w / 4); }
+
+int hevcdbk_h265_derive_bs_device(hevcdbk_context *ctx, const hevcdbk_h265_units *u, unsigned width, unsigned height,
+                                  uint8_t *vert_bs4, uint8_t *hor_bs4, uint8_t *chroma_vert_bs4, uint8_t *chroma_hor_bs4,
+                                  void *hip_stream)
+{
+    if (!ctx || !u || !u->flags || !u->mv0 || !u->mv1 || !u->ref0 || !u->ref1 || !vert_bs4 || !hor_bs4) return HEVCDBK_ERR_ARG;
+    if ((chroma_vert_bs4 != nullptr) != (chroma_hor_bs4 != nullptr)) return HEVCDBK_ERR_ARG;
+    if (width == 0 || height == 0 || width % 8 != 0 || height % 8 != 0) return HEVCDBK_ERR_DIMENSIONS;
+    if (chroma_vert_bs4 && ((width / 2) % 8 != 0 || (height / 2) % 8 != 0)) return HEVCDBK_ERR_DIMENSIONS;
+    if (int rc = bind(ctx)) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
+    const hipError_t e = dbk_launch_h265_bs(u->flags, u->mv0, u->mv1, u->ref0, u->ref1, (int)width, (int)height, vert_bs4,
+                                            hor_bs4, chroma_vert_bs4, chroma_hor_bs4, s);
+    return hip_ok(ctx, e, "bS derivation launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+}
+
+namespace {
+
+int h265_args(const hevcdbk_device_planes *planes, int c_idx, unsigned qp, const hevcdbk_h265_params *prm, DbkH265Args &h)
+{
+    if (!planes || c_idx < 0 || c_idx > 2 || (c_idx != 0) != (planes->is_chroma != 0)) return HEVCDBK_ERR_ARG;
+    const hevcdbk_h265_params zero = {0, 0, 0, 0};
+    if (!prm) prm = &zero;
+    if (prm->tc_offset_div2 < -6 || prm->tc_offset_div2 > 6 || prm->beta_offset_div2 < -6 || prm->beta_offset_div2 > 6 ||
+        prm->cb_qp_offset < -12 || prm->cb_qp_offset > 12 || prm->cr_qp_offset < -12 || prm->cr_qp_offset > 12)
+        return HEVCDBK_ERR_ARG;
+    if (planes->qp_map && (planes->ctu_log2 < 3 || planes->ctu_log2 > 8)) return HEVCDBK_ERR_ARG;
+    if (int rc = planes_to_args(planes, qp, nullptr, h.base)) return rc;
+    h.base.hstride = (int)(planes->plane_w / 4);
+    h.base.n_vert = (int)hevcdbk_h265_num_vert_bs(planes->plane_w, planes->plane_h);
+    h.base.n_hor = (int)hevcdbk_h265_num_hor_bs(planes->plane_w, planes->plane_h);
+    h.qp = (int)(qp > 51 ? 51 : qp);
+    h.tc_off = prm->tc_offset_div2 * 2;
+    h.beta_off = prm->beta_offset_div2 * 2;
+    h.c_qp_offset = c_idx == 1 ? prm->cb_qp_offset : (c_idx == 2 ? prm->cr_qp_offset : 0);
+    return HEVCDBK_OK;
+}
+
+int launch_h265(hevcdbk_context *ctx, const DbkH265Args &h, int sample_bytes, bool chroma, int variant, hipStream_t s)
+{
+    const bool can_pack = dbk_packed_h265_supports(h, sample_bytes, chroma);
+    hipError_t e;
+    if (variant == HEVCDBK_KERNEL_PACKED) {
+        if (!can_pack) return HEVCDBK_ERR_UNSUPPORTED;
+        e = dbk_launch_packed_h265(h, sample_bytes, chroma, s);
+    } else if (variant == HEVCDBK_KERNEL_GENERIC) {
+        e = dbk_launch_h265(h, sample_bytes, chroma, s);
+    } else if (variant == HEVCDBK_KERNEL_AUTO) {
+        e = can_pack ? dbk_launch_packed_h265(h, sample_bytes, chroma, s) : dbk_launch_h265(h, sample_bytes, chroma, s);
+    } else {
+        return HEVCDBK_ERR_ARG;
+    }
+    return hip_ok(ctx, e, "kernel launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+}
+
+} /* namespace */
+
+int hevc_deblocking_filter_h265_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, int c_idx, unsigned qp,
+                                       const hevcdbk_h265_params *params, int kernel_variant, void *hip_stream)
+{
+    if (!ctx) return HEVCDBK_ERR_ARG;
+    DbkH265Args h;
+    if (int rc = h265_args(planes, c_idx, qp, params, h)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
+    return launch_h265(ctx, h, (int)planes->sample_bytes, c_idx != 0, kernel_variant, s);
+}
+
+int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_h265_units *units,
+                                const hevcdbk_bs *bs4, const hevcdbk_qp *qp, const hevcdbk_h265_params *params,
+                                hevcdbk_timing *timing)
+{
+    if (!ctx || !frame || !qp || !frame->plane[0] || (units != nullptr) == (bs4 != nullptr)) return HEVCDBK_ERR_ARG;
+    if (bad_depth(frame->bit_depth, frame->sample_bytes)) return HEVCDBK_ERR_ARG;
+    const unsigned W = frame->width, H = frame->height, sb = frame->sample_bytes;
+    if (W == 0 || H == 0 || W % 8 != 0 || H % 8 != 0) return HEVCDBK_ERR_DIMENSIONS;
+    const bool chroma = frame->plane[1] && frame->plane[2];
+    if (chroma && ((W / 2) % 8 != 0 || (H / 2) % 8 != 0)) return HEVCDBK_ERR_DIMENSIONS;
+    const int npl = chroma ? 3 : 1;
+    const unsigned pw[3] = {W, W / 2, W / 2}, ph[3] = {H, H / 2, H / 2};
+    for (int i = 0; i < npl; i++)
+        if (frame->pitch[i] < (size_t)pw[i] * sb) return HEVCDBK_ERR_ARG;
+    const size_t nv = hevcdbk_h265_num_vert_bs(W, H), nh = hevcdbk_h265_num_hor_bs(W, H);
+    const size_t ncv = chroma ? hevcdbk_h265_num_vert_bs(W / 2, H / 2) : 0, nch = chroma ? hevcdbk_h265_num_hor_bs(W / 2, H / 2) : 0;
+    if (bs4) {
+        if (!bs4->vert || !bs4->hor) return HEVCDBK_ERR_ARG;
+        if (bs4->n_vert != nv || bs4->n_hor != nh) return HEVCDBK_ERR_BS_SIZE;
+    } else if (!units->flags || !units->mv0 || !units->mv1 || !units->ref0 || !units->ref1) {
+        return HEVCDBK_ERR_ARG;
+    }
+    size_t map_rows = 0;
+    if (qp->map) {
+        if (qp->ctu_log2 < 3 || qp->ctu_log2 > 8 || qp->map_stride < ((W + (1u << qp->ctu_log2) - 1) >> qp->ctu_log2))
+            return HEVCDBK_ERR_ARG;
+        map_rows = (H + (1u << qp->ctu_log2) - 1) >> qp->ctu_log2;
+    }
+    if (int rc = bind(ctx)) return rc;
+
+    size_t plane_bytes[3] = {0, 0, 0}, plane_off[3] = {0, 0, 0}, frame_bytes = 0;
+    for (int i = 0; i < npl; i++) {
+        plane_bytes[i] = (size_t)pw[i] * ph[i] * sb;
+        plane_off[i] = frame_bytes;
+        frame_bytes = (frame_bytes + plane_bytes[i] + 255) & ~(size_t)255;
+    }
+    if (int rc = grow_pinned(ctx, ctx->pin[0], frame_bytes)) return rc;
+    if (int rc = grow_device(ctx, ctx->dev[0], frame_bytes)) return rc;
+    if (int rc = grow_device(ctx, ctx->dev_bs, nv + nh + ncv + nch)) return rc;
+    ctx->bs_default_at = nullptr; /* dev_bs no longer holds the reference's default pattern */
+    if (qp->map)
+        if (int rc = grow_device(ctx, ctx->dev_map, map_rows * qp->map_stride)) return rc;
+    const size_t U = (size_t)(W / 4) * (H / 4);
+    if (units)
+        if (int rc = grow_device(ctx, ctx->dev_units, 18 * U)) return rc;
+    uint8_t *dbs = (uint8_t *)ctx->dev_bs.p, *dun = (uint8_t *)ctx->dev_units.p;
+    uint8_t *dmap = qp->map ? (uint8_t *)ctx->dev_map.p : nullptr;
+    hipStream_t s = ctx->compute;
+    hipEvent_t *ev = ctx->ev;
+
+    const auto wall0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < npl; i++) {
+        const size_t rb = (size_t)pw[i] * sb;
+        for (unsigned r = 0; r < ph[i]; r++)
+            std::memcpy((uint8_t *)ctx->pin[0].p + plane_off[i] + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
+    }
+    HIP_TRY(ctx, hipEventRecord(ev[0], s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[0].p, ctx->pin[0].p, frame_bytes, hipMemcpyHostToDevice, s));
+    if (dmap) HIP_TRY(ctx, hipMemcpyAsync(dmap, qp->map, map_rows * qp->map_stride, hipMemcpyHostToDevice, s));
+    if (units) {
+        /* device layout: ref0 | ref1 | mv0 | mv1 | flags (descending alignment) */
+        HIP_TRY(ctx, hipMemcpyAsync(dun, units->ref0, 4 * U, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(dun + 4 * U, units->ref1, 4 * U, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(dun + 8 * U, units->mv0, 4 * U, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(dun + 12 * U, units->mv1, 4 * U, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(dun + 16 * U, units->flags, 2 * U, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(dbs, bs4->vert, nv, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(dbs + nv, bs4->hor, nh, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(ctx, hipEventRecord(ev[1], s));
+    uint8_t *dcv = chroma ? dbs + nv + nh : nullptr, *dch = chroma ? dbs + nv + nh + ncv : nullptr;
+    hipError_t e;
+    if (units) e = dbk_launch_h265_bs(dun + 16 * U, dun + 8 * U, dun + 12 * U, dun, dun + 4 * U, (int)W, (int)H, dbs, dbs + nv, dcv, dch, s);
+    else e = chroma ? dbk_launch_h265_chroma_bs(dbs, dbs + nv, (int)W, (int)H, dcv, dch, s) : hipSuccess;
+    if (!hip_ok(ctx, e, "bS derivation launch")) return HEVCDBK_ERR_HIP;
+    for (int i = 0; i < npl; i++) {
+        hevcdbk_device_planes p;
+        std::memset(&p, 0, sizeof(p));
+        p.src = p.dst = (uint8_t *)ctx->dev[0].p + plane_off[i];
+        p.pitch = (size_t)pw[i] * sb; p.frame_stride = plane_bytes[i]; p.n_frames = 1;
+        p.plane_w = pw[i]; p.plane_h = ph[i]; p.bit_depth = frame->bit_depth; p.sample_bytes = sb;
+        p.is_chroma = i != 0;
+        p.vert_bs = i == 0 ? dbs : dcv;
+        p.hor_bs = i == 0 ? dbs + nv : dch;
+        p.qp_map = dmap; p.qp_map_stride = qp->map_stride; p.ctu_log2 = qp->ctu_log2;
+        DbkH265Args h;
+        if (int rc = h265_args(&p, i, qp->qp, params, h)) return rc;
+        if (int rc = launch_h265(ctx, h, (int)sb, i != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
+    }
+    HIP_TRY(ctx, hipEventRecord(ev[2], s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin[0].p, ctx->dev[0].p, frame_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(ev[3], s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    for (int i = 0; i < npl; i++) {
+        const size_t rb = (size_t)pw[i] * sb;
+        for (unsigned r = 0; r < ph[i]; r++)
+            std::memcpy((uint8_t *)frame->plane[i] + r * frame->pitch[i], (const uint8_t *)ctx->pin[0].p + plane_off[i] + r * rb, rb);
+    }
+    const auto wall1 = std::chrono::steady_clock::now();
+    if (timing) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, ev[1], ev[2]));
+        HIP_TRY(ctx, hipEventElapsedTime(&c, ev[2], ev[3]));
+        timing->exec_s = b * 1e-3;
+        timing->copy_s = (a + c) * 1e-3;
+        timing->total_s = timing->exec_s + timing->copy_s;
+        timing->pipelined_s = std::chrono::duration<double>(wall1 - wall0).count();
+    }
+    return HEVCDBK_OK;
+}
+
+/* ---- sample adaptive offset (H.265 clause 8.7.3) ------------------------------------------------------------- */
+
+static_assert(sizeof(hevcdbk_sao_ctb) == sizeof(DbkSaoCtb) && sizeof(DbkSaoCtb) == 6, "SAO CTB entry layout");
+
+int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p, const hevcdbk_sao_ctb *params,
+                           unsigned params_stride, size_t params_frame_stride, unsigned ctb_log2, const uint8_t *keep,
+                           unsigned keep_stride, size_t keep_frame_stride, void *hip_stream)
+{
+    if (!ctx || !p || !p->src || !p->dst || p->src == p->dst || !params) return HEVCDBK_ERR_ARG;
+    if (bad_depth(p->bit_depth, p->sample_bytes)) return HEVCDBK_ERR_ARG;
+    if (p->plane_w == 0 || p->plane_h == 0 || p->plane_w % 8 != 0 || p->plane_h % 8 != 0) return HEVCDBK_ERR_DIMENSIONS;
+    if (ctb_log2 < 3 || ctb_log2 > 6) return HEVCDBK_ERR_ARG;
+    if (params_stride < ((p->plane_w + (1u << ctb_log2) - 1) >> ctb_log2)) return HEVCDBK_ERR_ARG;
+    if (keep && keep_stride < p->plane_w / 8) return HEVCDBK_ERR_ARG;
+    const size_t align = 4 * p->sample_bytes;
+    if (p->pitch % align != 0 || p->frame_stride % align != 0 || (uintptr_t)p->src % align != 0 || (uintptr_t)p->dst % align != 0)
+        return HEVCDBK_ERR_UNSUPPORTED;
+    if (p->pitch < (size_t)p->plane_w * p->sample_bytes || p->n_frames > 65535 || p->plane_h > 65535) return HEVCDBK_ERR_ARG;
+    if (int rc = bind(ctx)) return rc;
+    DbkSaoArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.src = (const uint8_t *)p->src; a.dst = (uint8_t *)p->dst;
+    a.pitch = (long long)p->pitch; a.frame_stride = (long long)p->frame_stride;
+    a.plane_w = (int)p->plane_w; a.plane_h = (int)p->plane_h; a.n_frames = (int)p->n_frames;
+    a.max_v = (1 << p->bit_depth) - 1; a.band_shift = (int)p->bit_depth - 5;
+    a.params = reinterpret_cast<const DbkSaoCtb *>(params);
+    a.params_stride = (int)params_stride; a.params_frame_stride = (long long)params_frame_stride;
+    a.ctb_log2 = (int)ctb_log2;
+    a.keep = keep; a.keep_stride = (int)keep_stride; a.keep_frame_stride = (long long)keep_frame_stride;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
+    return hip_ok(ctx, dbk_launch_sao(a, (int)p->sample_bytes, s), "SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+}
+
+} /* extern "C" */
