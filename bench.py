@@ -6,9 +6,11 @@ A "step" = one launch of hevc_deblocking_filter_device over a batch of F distinc
 bS, out of place src -> dst so every step sees the same input).  F x 8.3 MB x 2 >> 256 MB, so the
 Infinity Cache cannot hold the working set (SURVEY 7 "hard parts").
 
-Multi-GPU: one process per GPU (torch.distributed.run); frames shard frame-parallel with NO
-data-path collective -- torch.distributed (gloo) is used only for the barrier and the
-max-over-ranks of the elapsed time.  Scaling is weak: every rank filters its own F frames.
+Multi-GPU: one process per GPU -- either started by torch.distributed.run (RANK / WORLD_SIZE in the
+environment) or, for a bare `python bench.py --gpus N`, by this script itself (shard.spawn_ranks: N child
+processes, never an exec).  Frames shard frame-parallel with NO data-path collective (SURVEY 8e);
+torch.distributed (gloo) is used only for the barrier and the max-over-ranks of the elapsed time.
+Scaling is weak: every rank filters its own F frames.
 
 Prints ONE JSON line on rank 0.
 """
@@ -139,6 +141,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process becomes the launcher.  It has made no HIP call (the
+        # product library is not even loaded yet) and never execs: it starts N fresh children of this script,
+        # one rank per GPU, waits for all of them and fails if any fails.  Rank 0 prints the one JSON line.
+        codes = shard.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        bad = [c for c in codes if c != 0]
+        if bad:
+            print("bench: rank exit codes %s" % codes, file=sys.stderr)
+            raise SystemExit(bad[0] if 0 < bad[0] < 256 else 1)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

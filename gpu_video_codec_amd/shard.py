@@ -2,7 +2,68 @@
 
 torch.distributed is used for the control plane only (barrier, max over ranks of a timing); the data
 path has no collective.  Pure host logic -- exercised by world_size-2 gloo tests on CPU.
+
+This module imports nothing that touches a GPU: `spawn_ranks` must be callable from a parent process
+that has not initialised HIP (a process that has may neither fork safely nor exec).
 """
+import os
+import socket
+import subprocess
+import sys
+import time
+
+
+def free_port():
+    """A TCP port nobody listens on right now, on the loopback interface the rendezvous uses."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_env(rank, world, port, base=None):
+    """Environment of rank `rank` of a one-node, one-process-per-GPU job (what torch.distributed.run sets)."""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def spawn_ranks(world, argv, timeout_s=None, poll_s=0.05):
+    """Start `world` fresh child processes of `argv` (rank r gets rank_env(r)), wait for all of them and return
+    the list of exit codes.  Never an exec of the caller: children are ordinary subprocesses, stdout / stderr
+    inherited (rank 0 prints the job's one JSON line).  As soon as one child fails -- or the timeout expires --
+    the remaining children (exactly the PIDs started here) are terminated, so that a rank waiting in a barrier
+    for a dead peer cannot hang the job; their exit code is then reported as non-zero too."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    port = free_port()
+    procs = [subprocess.Popen(list(argv), env=rank_env(r, world, port)) for r in range(world)]
+    t0 = time.monotonic()
+    failed = False
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes) or (timeout_s is not None and time.monotonic() - t0 > timeout_s):
+            failed = True
+            break
+        time.sleep(poll_s)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    codes = [p.returncode for p in procs]
+    if failed and all(c == 0 for c in codes):  # timeout with every child exiting 0 at the last moment
+        codes[0] = 124
+    return codes
 
 
 def frames_of_rank(n_frames, rank, world):

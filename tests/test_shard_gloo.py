@@ -67,3 +67,104 @@ def test_shard_map_properties():
         shard.frames_of_rank(4, 2, 2)
     with pytest.raises(RuntimeError):
         shard.gather_frame_results(None, {0: "a"}, 2)
+
+
+# ---- the launcher of `python bench.py --gpus N` (shard.spawn_ranks) ------------------------------------
+
+_CHILD_OK = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from gpu_video_codec_amd import shard
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(rank) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dist.barrier()
+t = shard.max_over_ranks(dist, 10.0 + rank)
+dist.barrier()
+dist.destroy_process_group()
+with open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w") as fh:
+    json.dump({"rank": rank, "world": world, "tmax": t, "pid": os.getpid(), "ppid": os.getppid()}, fh)
+"""
+
+_CHILD_FAIL = r"""
+import os, sys, time
+if os.environ["RANK"] == "1":
+    sys.exit(7)          # one rank dies before the rendezvous ...
+time.sleep(600)          # ... the others would wait for it forever
+"""
+
+
+def test_spawn_ranks_starts_n_fresh_processes(tmp_path):
+    import json
+    from gpu_video_codec_amd import shard
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD_OK % {"root": ROOT, "out": str(tmp_path)})
+    codes = shard.spawn_ranks(3, [sys.executable, str(script)], timeout_s=240)
+    assert codes == [0, 0, 0]
+    got = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(3)]
+    assert [g["rank"] for g in got] == [0, 1, 2] and all(g["world"] == 3 for g in got)
+    assert all(g["tmax"] == 12.0 for g in got)                     # max over ranks of 10 + rank
+    assert len({g["pid"] for g in got}) == 3                       # three distinct processes ...
+    assert all(g["ppid"] == os.getpid() and g["pid"] != os.getpid() for g in got)  # ... children, not an exec of the caller
+
+
+def test_spawn_ranks_fails_when_a_rank_fails(tmp_path):
+    import time
+    from gpu_video_codec_amd import shard
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD_FAIL)
+    t0 = time.monotonic()
+    codes = shard.spawn_ranks(2, [sys.executable, str(script)], timeout_s=120)
+    assert time.monotonic() - t0 < 60        # the surviving rank was terminated, not waited for
+    assert codes[1] == 7 and codes[0] != 0
+
+
+def test_bench_gpus_flag_spawns_before_any_gpu_call(tmp_path, monkeypatch):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must hand over to shard.spawn_ranks with the same
+    arguments BEFORE the product library is loaded (no HIP call in the launcher); under torch.distributed.run
+    (WORLD_SIZE set) it must not spawn again."""
+    import importlib.util
+    from gpu_video_codec_amd import _lib, shard
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    def fake_spawn(world, argv, **kw):
+        calls.append((world, list(argv), None))
+        return [0] * world
+
+    monkeypatch.setattr(shard, "spawn_ranks", fake_spawn)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    bench.main()
+    assert len(calls) == 1
+    world, argv, _ = calls[0]
+    assert world == 2 and argv[0] == sys.executable and argv[1].endswith("bench.py")
+    assert argv[2:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+
+    def failing_spawn(world, argv, **kw):
+        return [0, 3]
+
+    monkeypatch.setattr(shard, "spawn_ranks", failing_spawn)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3
+
+    # in a fresh interpreter: at the moment of the hand-over the product library (and with it the HIP runtime)
+    # has not been loaded
+    import subprocess
+    probe = (
+        "import sys, importlib.util; sys.argv = ['bench.py', '--gpus', '2']\n"
+        "spec = importlib.util.spec_from_file_location('b', %r); b = importlib.util.module_from_spec(spec)\n"
+        "spec.loader.exec_module(b)\n"
+        "from gpu_video_codec_amd import shard, _lib\n"
+        "def fake(world, argv, **kw):\n"
+        "    print('LOADED' if _lib._lib is not None else 'NOTLOADED'); return [0] * world\n"
+        "shard.spawn_ranks = fake\n"
+        "b.main()\n" % os.path.join(ROOT, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == "NOTLOADED"
