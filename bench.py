@@ -136,7 +136,12 @@ def main():
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--variant", choices=["auto", "generic", "packed", "copy"], default="auto",
-                    help="copy = diagnostic memory-path ablation (dst = src, no filter); never a benchmark result")
+                    help="copy = diagnostic memory-path ablation (dst = src, no filter), runs on libhevcdbk_diag.so; "
+                         "never a benchmark result")
+    ap.add_argument("--map", choices=["auto", "rows", "linear"], default="auto",
+                    help="block -> lane map of the packed kernels (HEVCDBK_MAP_*; same bytes either way)")
+    ap.add_argument("--diag", default=None,
+                    help="load libhevcdbk_diag.so and set these knobs (csrc/hevcdbk_diag.h): A/B runs only, never a result")
     ap.add_argument("--cpu-budget-s", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -163,8 +168,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    if args.variant == "copy" or args.diag is not None:
+        _lib.use_diagnostic_library(args.diag)
     variant = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "packed": _lib.KERNEL_PACKED,
-               "copy": _lib.KERNEL_DIAG_COPY}[args.variant]
+               "copy": _lib.DIAG_KERNEL_COPY}[args.variant]
+    variant |= {"auto": _lib.MAP_AUTO, "rows": _lib.MAP_ROWS, "linear": _lib.MAP_LINEAR}[args.map]
     w, h, F, bd = args.width, args.height, args.frames, args.bit_depth
     sb = 1 if bd == 8 else 2
     ndev = deblock.device_count()
@@ -214,7 +222,8 @@ def main():
         "dtype": "int32" if args.variant == "generic" else "int16", "data": "synthetic",
         "config": {"workload": "synthetic %dx%d %d-bit luma deblock, QP %d, default bS, %d frames/GPU/step, device-resident, src->dst"
                                % (w, h, bd, args.qp, F),
-                   "frames_per_gpu": F, "kernel_variant": args.variant, "settle_launches": args.settle, "parallelism": "frame-parallel x%d, no collective" % world},
+                   "frames_per_gpu": F, "kernel_variant": args.variant, "block_map": args.map, "diag": args.diag,
+                   "settle_launches": args.settle, "parallelism": "frame-parallel x%d, no collective" % world},
         "bit_exact_vs_oracle": bit_exact, "diagnostic_copy_only": args.variant == "copy",
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic[0] if traffic else None,

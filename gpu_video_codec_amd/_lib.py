@@ -13,7 +13,10 @@ LIB_PATH = os.path.join(_HERE, "libhevcdbk.so")
 OK, ERR_FILE_SIZE, ERR_DIMENSIONS, ERR_BS_SIZE, ERR_HIP, ERR_ARG, ERR_NOMEM, ERR_IO, ERR_UNSUPPORTED = \
     0, -1, -2, -3, -4, -5, -6, -7, -8
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED = 0, 1, 2
-KERNEL_DIAG_COPY = 100
+MAP_AUTO, MAP_ROWS, MAP_LINEAR = 0x000, 0x100, 0x200   # OR-ed into the kernel selector (HEVCDBK_MAP_*)
+# diagnostic library only (csrc/hevcdbk_diag.h; use_diagnostic_library() below): the product library refuses it
+DIAG_KERNEL_COPY = 100
+DIAG_LIB_PATH = os.path.join(_HERE, "libhevcdbk_diag.so")
 
 # every symbol include/hevc_deblock.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -87,6 +90,22 @@ class DeviceInfo(C.Structure):
 
 
 _lib = None
+
+
+def use_diagnostic_library(spec=None):
+    """Tools and ablation tests only: make this process load libhevcdbk_diag.so (the same sources built with
+    -DHEVCDBK_DIAG: copy variant, timing-only ablations, launch knobs) instead of the product library, and set its
+    knobs (hevcdbk_diag_set).  Must be called before the first use of the library; never called by the product path."""
+    global LIB_PATH
+    if _lib is not None and LIB_PATH != DIAG_LIB_PATH:
+        raise RuntimeError("the product library is already loaded in this process")
+    LIB_PATH = DIAG_LIB_PATH
+    L = lib()
+    L.hevcdbk_diag_set.argtypes = [C.c_char_p]
+    rc = L.hevcdbk_diag_set(None if spec is None else spec.encode())
+    if rc != OK:
+        raise ValueError("hevcdbk_diag_set(%r) -> %d" % (spec, rc))
+    return L
 
 
 def lib():

@@ -52,6 +52,6 @@ bool is_pinned_host(const void *p);
 int check_frame(const hevcdbk_frame &f, bool &chroma);
 int check_bs(const hevcdbk_bs *bs, unsigned W, unsigned H, bool chroma);
 int planes_to_args(const hevcdbk_device_planes *p, unsigned qp, const hevcdbk_tables *tables, DbkArgs &a);
-int launch(hevcdbk_context *ctx, const DbkArgs &a, int sample_bytes, bool chroma, int variant, hipStream_t s);
+int launch(hevcdbk_context *ctx, const DbkArgs &a0, int sample_bytes, bool chroma, int variant, hipStream_t s);
 
 } /* namespace dbkh */

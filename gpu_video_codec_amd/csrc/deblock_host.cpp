@@ -27,6 +27,9 @@
 #include <vector>
 
 #include "deblock_ctx.h"
+#ifdef HEVCDBK_DIAG
+#include "hevcdbk_diag.h"
+#endif
 
 namespace {
 
@@ -188,12 +191,24 @@ int planes_to_args(const hevcdbk_device_planes *p, unsigned qp, const hevcdbk_ta
     return fill_tables(a, tables, qp, p->bit_depth);
 }
 
-int launch(hevcdbk_context *ctx, const DbkArgs &a, int sample_bytes, bool chroma, int variant, hipStream_t s)
+int launch(hevcdbk_context *ctx, const DbkArgs &a0, int sample_bytes, bool chroma, int variant, hipStream_t s)
 {
     hipError_t e;
-    if (variant == HEVCDBK_KERNEL_PACKED || variant == HEVCDBK_KERNEL_DIAG_COPY) {
+    /* bits 8..9 of the selector: block -> lane map of the packed kernels (HEVCDBK_MAP_*); same bytes either way */
+    const int map = variant & HEVCDBK_MAP_MASK;
+    variant &= ~HEVCDBK_MAP_MASK;
+    if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR) return HEVCDBK_ERR_ARG;
+    DbkArgs a = a0;
+    a.map_override = map == HEVCDBK_MAP_ROWS ? 1 : (map == HEVCDBK_MAP_LINEAR ? 2 : 0);
+#ifdef HEVCDBK_DIAG
+    if (variant == HEVCDBK_DIAG_KERNEL_COPY) {
         if (!dbk_packed_supports(a, sample_bytes, chroma)) return HEVCDBK_ERR_UNSUPPORTED;
-        e = dbk_launch_packed(a, sample_bytes, chroma, variant == HEVCDBK_KERNEL_DIAG_COPY ? 1 : 0, s);
+        e = dbk_launch_packed(a, sample_bytes, chroma, 1, s);
+    } else
+#endif
+    if (variant == HEVCDBK_KERNEL_PACKED) {
+        if (!dbk_packed_supports(a, sample_bytes, chroma)) return HEVCDBK_ERR_UNSUPPORTED;
+        e = dbk_launch_packed(a, sample_bytes, chroma, 0, s);
     } else if (variant == HEVCDBK_KERNEL_GENERIC) {
         e = dbk_launch_generic(a, sample_bytes, chroma, s);
     } else if (variant == HEVCDBK_KERNEL_AUTO) {
@@ -204,6 +219,41 @@ int launch(hevcdbk_context *ctx, const DbkArgs &a, int sample_bytes, bool chroma
     }
     return hip_ok(ctx, e, "kernel launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
 }
+
+#ifdef HEVCDBK_DIAG
+/* hevcdbk_diag.h: the knobs of the diagnostic library (never compiled into libhevcdbk.so) */
+extern "C" HEVCDBK_API int hevcdbk_diag_set(const char *spec)
+{
+    DbkDiag d = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const std::string sp = spec ? spec : "";
+    size_t i = 0;
+    while (i < sp.size()) {
+        size_t j = sp.find(',', i);
+        if (j == std::string::npos) j = sp.size();
+        const std::string tok = sp.substr(i, j - i);
+        i = j + 1;
+        if (tok.empty()) continue;
+        if (tok == "noswz") d.noswz = 1;
+        else if (tok == "nofuse") d.nofuse = 1;
+        else if (tok == "dmacopy") d.dmacopy = 1;
+        else if (tok == "nostrong") d.ablate = 1;
+        else if (tok == "nonormal") d.ablate = 2;
+        else if (tok == "barriers") d.ablate = 4;
+        else if (tok == "queue") d.queue = 1;
+        else if (tok == "align") d.align = 1;
+        else if (tok == "mode3") d.mode3 = 1;
+        else if (tok.compare(0, 5, "prio=") == 0) d.prio = std::atoi(tok.c_str() + 5) & 3;
+        else if (tok.compare(0, 6, "dummy=") == 0) d.dummy = std::atoi(tok.c_str() + 6);
+        else if (tok.compare(0, 3, "wg=") == 0) {
+            const int c = std::atoi(tok.c_str() + 3) / 64 * 64;
+            if (c < 64 || c > 1024) return HEVCDBK_ERR_ARG;
+            d.wg_cap = c;
+        } else return HEVCDBK_ERR_ARG;
+    }
+    g_dbk_diag = d;
+    return HEVCDBK_OK;
+}
+#endif
 
 /*
  * Put the frame's bS arrays (luma vert | luma hor | chroma vert | chroma hor) into ctx->dev_bs on stream `s`.
@@ -564,8 +614,11 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
     bool zc[3] = {false, false, false};
     if (!small)
         for (int i = 0; i < npl; i++) zc[i] = is_pinned_host(frame->plane[i]);
-    /* HEVCDBK_TUNE=dmacopy: small frames through DMA copies around the kernel instead (for A/B runs) */
-    static const bool host_direct = [] { const char *e = std::getenv("HEVCDBK_TUNE"); return !(e && std::strstr(e, "dmacopy") != nullptr); }();
+#ifdef HEVCDBK_DIAG /* "dmacopy": small frames through DMA copies around the kernel instead (for A/B runs) */
+    const bool host_direct = !g_dbk_diag.dmacopy;
+#else
+    constexpr bool host_direct = true;
+#endif
     if (small && host_direct) {
         /*
          * Small frame: no DMA at all.  The staging buffer is page-locked, fine-grained host memory the GPU can address, so

@@ -53,8 +53,13 @@ int h265_args(const hevcdbk_device_planes *planes, int c_idx, unsigned qp, const
     return HEVCDBK_OK;
 }
 
-int launch_h265(hevcdbk_context *ctx, const DbkH265Args &h, int sample_bytes, bool chroma, int variant, hipStream_t s)
+int launch_h265(hevcdbk_context *ctx, const DbkH265Args &h0, int sample_bytes, bool chroma, int variant, hipStream_t s)
 {
+    const int map = variant & HEVCDBK_MAP_MASK; /* as in dbkh::launch */
+    variant &= ~HEVCDBK_MAP_MASK;
+    if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR) return HEVCDBK_ERR_ARG;
+    DbkH265Args h = h0;
+    h.base.map_override = map == HEVCDBK_MAP_ROWS ? 1 : (map == HEVCDBK_MAP_LINEAR ? 2 : 0);
     const bool can_pack = dbk_packed_h265_supports(h, sample_bytes, chroma);
     hipError_t e;
     if (variant == HEVCDBK_KERNEL_PACKED) {

@@ -26,9 +26,15 @@ struct DbkArgs {
     int nb_total, wpf;              /* blocks per frame, workgroups per frame */
     uint32_t magic_wpf, magic_nbx;  /* floor(2^32/d)+1 reciprocals */
     int xcd_swizzle;                /* renumber workgroups so each XCD gets a contiguous range */
+    int map_override;               /* block -> lane map of the packed kernels: 0 = chosen from the geometry, 1 = one
+                                       workgroup per block row, 2 = row-major numbering (HEVCDBK_MAP_* of the C ABI) */
+#ifdef HEVCDBK_DIAG /* the diagnostic build only (libhevcdbk_diag.so, hevcdbk_diag.h): never in the product library */
     int use_queue;   /* 8-bit luma: strong segments scheduled through the workgroup's LDS queue */
-    int diag_ablate; /* diagnostic: 1 = strong segments filtered as normal, 2 = normal filter skipped (wrong pixels) */
-    int diag_xshift; /* diagnostic copy mode only: byte shift of every row span (alignment experiments) */
+    int diag_ablate; /* 1 = strong segments filtered as normal, 2 = normal filter skipped, 4 = barriers (WRONG pixels) */
+    int diag_xshift; /* copy mode only: byte shift of every row span (alignment experiments) */
+    int diag_prio;   /* bit 0: s_setprio 3 from wave start until the row loads are issued; bit 1: from the final pack on */
+    int diag_dummy;  /* N extra VALU instructions per wave (sensitivity of the kernel time to VALU work) */
+#endif
     /* launch only the block rows by_begin .. by_begin + by_count - 1 (by_count 0 = all): a frame's block rows are
      * independent, so a host pipeline can filter a frame strip by strip while the other strips are still on the bus */
     int by_begin, by_count;
@@ -41,7 +47,7 @@ void dbk_set_next_launch_events(hipEvent_t start, hipEvent_t stop);
 /* one lane per offset block, 32-bit arithmetic; every operand kind */
 hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, hipStream_t stream);
 /* packed int16 arithmetic kernels: scalar QP; 8-bit samples (luma or chroma) and 16-bit containers (luma) */
-/* mode 0 = filter, 1 = diagnostic copy (same memory accesses, no arithmetic) */
+/* mode 0 = filter; 1 = diagnostic copy (same memory accesses, no arithmetic) exists in the HEVCDBK_DIAG build only */
 hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, int mode, hipStream_t stream);
 bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma);
 
@@ -52,6 +58,24 @@ struct DbkMultiArgs {
 };
 bool dbk_multi_supports(const DbkArgs *planes, int n, const int *sample_bytes);
 hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t stream);
+
+#ifdef HEVCDBK_DIAG
+/* knobs of the diagnostic build, set through hevcdbk_diag_set() (hevcdbk_diag.h); the product library has none of this and
+ * reads no environment variable */
+struct DbkDiag {
+    int wg_cap;    /* workgroup width cap of the packed kernels (64..1024), default 512 */
+    int noswz;     /* row-major map without the per-XCD renumbering */
+    int nofuse;    /* no fused Y+U+V launch */
+    int dmacopy;   /* small frames through DMA copies instead of host-direct kernels */
+    int ablate;    /* 1 nostrong, 2 nonormal, 4 barriers: WRONG pixels, timing only */
+    int queue;     /* the LDS-queue kernel for 8-bit luma */
+    int align;     /* copy mode: shift the row spans onto their natural alignment */
+    int prio;      /* wave priority experiment, see DbkArgs::diag_prio */
+    int dummy;     /* extra VALU instructions per wave */
+    int mode3;     /* run the instrumented (MODE 3) instantiation even with no ablation set: the A/B baseline */
+};
+extern DbkDiag g_dbk_diag;
+#endif
 
 /* ---- spec-exact mode (H.265 clause 8.7.2), deblock_h265.hip ---- */
 struct DbkH265Args {

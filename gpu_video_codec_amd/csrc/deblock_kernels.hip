@@ -278,7 +278,11 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
     const bool lv = active && bx > 0;            /* cols 0..3 inside the image */
     const bool rv = active && bx < a.nbx - 1;    /* cols 4..7 inside the image */
     const int y0 = by * 8 - 4;
+#ifdef HEVCDBK_DIAG
     const uint32_t xoff = (uint32_t)(bx * 8 - 4) + (MODE == 1 ? (uint32_t)a.diag_xshift : 0u);
+#else
+    const uint32_t xoff = (uint32_t)(bx * 8 - 4);
+#endif
     const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -287,6 +291,11 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         a.dst + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
 
     uint32_t L[8], R[8];
+#ifdef HEVCDBK_DIAG
+    if constexpr (MODE == 3) {
+        if (a.diag_prio & 1) __builtin_amdgcn_s_setprio(3);
+    }
+#endif
     if constexpr (PATH == 0) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -321,7 +330,20 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
     if constexpr (MODE == 0 || MODE == 3) { /* 3 = the filter with the timing-only ablation switches compiled in */
         const dbk::BlockBs bs = load_bs_buffer<PATH != 0>(a, f, by, bx, active);
         const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
+#ifdef HEVCDBK_DIAG
+        if constexpr (MODE == 3) {
+            if (a.diag_prio & 1) __builtin_amdgcn_s_setprio(0);
+            uint32_t sink = L[0];
+            for (int i = 0; i < a.diag_dummy; i++) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(sink) : "v"(R[0]));
+            if (a.diag_dummy && sink == 0x12345678u) L[0] ^= 1u; /* keeps the chain alive; never true for packed samples */
+        }
         dbk::packed_filter_block<CHROMA>(L, R, bs, q, MODE == 3 ? a.diag_ablate : 0);
+        if constexpr (MODE == 3) {
+            if (a.diag_prio & 2) __builtin_amdgcn_s_setprio(3);
+        }
+#else
+        dbk::packed_filter_block<CHROMA>(L, R, bs, q);
+#endif
     } else if constexpr (MODE == 2) { /* spec-exact mode, H.265 8.7.2 */
         int entry[4];
         load_bs_buffer_h265<PATH>(a, f, by, bx, active, entry);
@@ -394,7 +416,11 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
     const bool lv = active && bx > 0;
     const bool rv = active && bx < a.nbx - 1;
     const int y0 = by * 8 - 4;
+#ifdef HEVCDBK_DIAG
     const uint32_t xoff = (uint32_t)(bx * 16 - 8) + (MODE == 1 ? (uint32_t)a.diag_xshift : 0u);
+#else
+    const uint32_t xoff = (uint32_t)(bx * 16 - 8);
+#endif
     const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -630,6 +656,7 @@ __global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiAr
     }
 }
 
+#ifdef HEVCDBK_DIAG /* measured and rejected; kept in the diagnostic build for A/B runs */
 /* ------------------------------------------------------------------------------------------ */
 /* 8-bit luma with workgroup-level scheduling of the strong filter                              */
 /*
@@ -881,12 +908,26 @@ __global__ __launch_bounds__(WG) void dbk_packed_q_kernel(const DbkArgs a)
     }
 }
 
+#endif /* HEVCDBK_DIAG */
+
 } /* namespace */
+
+/* largest tc (scaled to the bit depth) a lane of this launch can be handed: the scalar-QP value, or with a QP map any
+ * entry of the table */
+static int max_scaled_tc(const DbkArgs &a)
+{
+    if (!a.qp_map) return a.tc;
+    int m = 0;
+    for (int i = 0; i < 52; i++) m = a.tc_tab[i] > m ? a.tc_tab[i] : m;
+    return m << a.shift;
+}
 
 bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
 {
     /* the packed kernels address a plane through a buffer resource with 32-bit offsets */
     if ((unsigned long long)a.pitch * (unsigned long long)a.plane_h >= (1ull << 31)) return false;
+    /* caller-supplied tc tables may exceed what the 16-bit fields of the luma core hold (deblock_packed.h) */
+    if (!chroma && !dbk::packed_luma_tc_fits(a.max_v, max_scaled_tc(a))) return false;
     if (sample_bytes == 1) return a.max_v == 255;                /* 8-bit: luma and chroma */
     /* 16-bit containers up to 12 bit.  Luma: up to 11 bit every intermediate fits int16 (the normal filter's
      * 9*(q0-p0) - 3*(q1-p1) + 8 needs 12*max_v + 8 <= 32767); 12 bit runs the WIDE variant of the core.
@@ -895,47 +936,46 @@ bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
            ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0;
 }
 
-/* development knob: HEVCDBK_WG caps the workgroup width.  (The non-temporal load/store variants -- template parameter
- * NT of the bodies -- measured slower on MI355X and are no longer instantiated.) */
-static int tune_wg_cap()
-{
-    static const int v = [] {
-        const char *e = getenv("HEVCDBK_WG");
-        int c = e ? atoi(e) / 64 * 64 : 512;
-        return c < 64 ? 64 : (c > 1024 ? 1024 : c);
-    }();
-    return v;
-}
-
-static bool tune_rowmap()
-{
-    static const bool v = [] { const char *e = getenv("HEVCDBK_TUNE"); return e && strstr(e, "rowmap") != nullptr; }();
-    return v;
-}
+#ifdef HEVCDBK_DIAG
+DbkDiag g_dbk_diag = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static int wg_cap() { return g_dbk_diag.wg_cap; }
+#else
+/* workgroup width cap of the packed kernels (measured best on MI355X; the diagnostic build can vary it) */
+static constexpr int wg_cap() { return 512; }
+#endif
 
 template <bool NT, bool LINEAR>
 static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int mode, dim3 grid, dim3 block, hipStream_t stream)
 {
     const bool qm = a.qp_map != nullptr;
-    if (sample_bytes == 2 && chroma && mode == 0) {
+#ifdef HEVCDBK_DIAG
+    if (mode == 1) { /* copy: the kernel's loads and stores, no arithmetic */
+        if (sample_bytes == 2) DBK_LAUNCH((dbk_packed16_kernel<1, NT, LINEAR, false>), grid, block, stream, a);
+        else DBK_LAUNCH((dbk_packed_kernel<false, 1, NT, LINEAR, false>), grid, block, stream, a);
+        return;
+    }
+    if (sample_bytes == 1 && !chroma && !qm && a.use_queue && block.x <= 512) {
+        if (block.x <= 128) DBK_LAUNCH((dbk_packed_q_kernel<NT, LINEAR, 128>), grid, block, stream, a);
+        else if (block.x <= 256) DBK_LAUNCH((dbk_packed_q_kernel<NT, LINEAR, 256>), grid, block, stream, a);
+        else DBK_LAUNCH((dbk_packed_q_kernel<NT, LINEAR, 512>), grid, block, stream, a);
+        return;
+    }
+    if (sample_bytes == 1 && !chroma && !qm && (a.diag_ablate || a.diag_prio || a.diag_dummy || g_dbk_diag.mode3)) { /* timing only */
+        DBK_LAUNCH((dbk_packed_kernel<false, 3, NT, LINEAR, false>), grid, block, stream, a);
+        return;
+    }
+#endif
+    (void)mode;
+    if (sample_bytes == 2 && chroma) {
         if (qm) DBK_LAUNCH((dbk_packed16c_kernel<LINEAR, true>), grid, block, stream, a);
         else DBK_LAUNCH((dbk_packed16c_kernel<LINEAR, false>), grid, block, stream, a);
     } else if (sample_bytes == 2) {
-        if (mode == 1) DBK_LAUNCH((dbk_packed16_kernel<1, NT, LINEAR, false>), grid, block, stream, a);
-        else if (a.max_v > 2047) { /* 12 bit: the WIDE variant of the core (deblock_packed.h) */
+        if (a.max_v > 2047) { /* 12 bit: the WIDE variant of the core (deblock_packed.h) */
             if (qm) DBK_LAUNCH((dbk_packed16_kernel<0, NT, LINEAR, true, true>), grid, block, stream, a);
             else DBK_LAUNCH((dbk_packed16_kernel<0, NT, LINEAR, false, true>), grid, block, stream, a);
         } else if (qm) DBK_LAUNCH((dbk_packed16_kernel<0, NT, LINEAR, true>), grid, block, stream, a);
         else DBK_LAUNCH((dbk_packed16_kernel<0, NT, LINEAR, false>), grid, block, stream, a);
-    } else if (mode == 0 && !chroma && !qm && a.use_queue && block.x <= 512) {
-        if (block.x <= 128) DBK_LAUNCH((dbk_packed_q_kernel<NT, LINEAR, 128>), grid, block, stream, a);
-        else if (block.x <= 256) DBK_LAUNCH((dbk_packed_q_kernel<NT, LINEAR, 256>), grid, block, stream, a);
-        else DBK_LAUNCH((dbk_packed_q_kernel<NT, LINEAR, 512>), grid, block, stream, a);
-    } else if (mode == 1)
-        DBK_LAUNCH((dbk_packed_kernel<false, 1, NT, LINEAR, false>), grid, block, stream, a);
-    else if (mode == 0 && !chroma && !qm && a.diag_ablate) /* HEVCDBK_TUNE=nostrong|nonormal|barriers: wrong pixels, timing only */
-        DBK_LAUNCH((dbk_packed_kernel<false, 3, NT, LINEAR, false>), grid, block, stream, a);
-    else if (chroma) {
+    } else if (chroma) {
         if (qm) DBK_LAUNCH((dbk_packed_kernel<true, 0, NT, LINEAR, true>), grid, block, stream, a);
         else DBK_LAUNCH((dbk_packed_kernel<true, 0, NT, LINEAR, false>), grid, block, stream, a);
     } else {
@@ -948,7 +988,7 @@ static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int
  * dimensions; returns true for the row-major (LINEAR) map, false for one workgroup per block row */
 static bool plan_packed(const DbkArgs &a, DbkArgs &b, dim3 &grid, dim3 &block)
 {
-    const int cap = tune_wg_cap();
+    const int cap = wg_cap();
     const long long nb = (long long)a.nbx * a.nby;
     /* row-major block numbering needs exact 32-bit reciprocal division: dividends < 2^32 / divisor */
     const int wg = (int)(nb < cap ? (nb + 63) / 64 * 64 : cap);
@@ -957,16 +997,20 @@ static bool plan_packed(const DbkArgs &a, DbkArgs &b, dim3 &grid, dim3 &block)
     /* reciprocal division floor(2^32/d)+1 is exact for dividends < 2^32/d and needs d >= 2 */
     /* measured on MI355X: when a whole block row fits one workgroup (4K: 481 blocks) the row mapping wins
      * (3.96 vs 3.69 TB/s at 4K 8-bit, idle lanes included); wider rows (8K: 961 blocks) do better row-major
-     * (5.06 vs 4.89 TB/s at 8K 10-bit).  HEVCDBK_TUNE=rowmap / linear force either for A/B runs. */
-    const char *tune = getenv("HEVCDBK_TUNE");
+     * (5.06 vs 4.89 TB/s at 8K 10-bit).  a.map_override (HEVCDBK_MAP_ROWS / HEVCDBK_MAP_LINEAR of the C ABI) forces
+     * either; both give the same bytes. */
     /* a block-row range (strip launches of the host pipeline) always takes the row map */
-    const bool want_linear = a.by_count == 0 && ((tune && strstr(tune, "linear")) || (!tune_rowmap() && a.nbx > cap));
+    const bool want_linear = a.by_count == 0 && (a.map_override == 2 || (a.map_override != 1 && a.nbx > cap));
     const bool linear = want_linear && wpf >= 2 && a.nbx >= 2 && (nb + 1024) * a.nbx < (1ll << 32) &&
                         total * wpf < (1ll << 32) && total < (1ll << 31);
     if (linear) {
         b.nb_total = (int)nb;
         b.wpf = (int)wpf;
-        b.xcd_swizzle = !(tune && strstr(tune, "noswz"));
+#ifdef HEVCDBK_DIAG
+        b.xcd_swizzle = !g_dbk_diag.noswz;
+#else
+        b.xcd_swizzle = 1;
+#endif
         b.magic_wpf = (uint32_t)((1ull << 32) / (unsigned long long)wpf + 1ull);
         b.magic_nbx = (uint32_t)((1ull << 32) / (unsigned long long)a.nbx + 1ull);
         block = dim3(wg, 1, 1);
@@ -984,12 +1028,15 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
 {
     if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
     DbkArgs b = a;
-    { const char *e = getenv("HEVCDBK_TUNE"); b.diag_ablate = e && strstr(e, "nostrong") ? 1 : (e && strstr(e, "nonormal") ? 2 : (e && strstr(e, "barriers") ? 4 : 0)); }
-    { const char *e = getenv("HEVCDBK_TUNE"); b.use_queue = (e && strstr(e, "queue")) ? 1 : 0; }
-    if (mode == 1) { /* diagnostic copy only: HEVCDBK_TUNE=align shifts the spans onto their natural alignment */
-        const char *e = getenv("HEVCDBK_TUNE");
-        b.diag_xshift = (e && strstr(e, "align")) ? 4 * sample_bytes : 0;
-    }
+#ifdef HEVCDBK_DIAG
+    b.diag_ablate = g_dbk_diag.ablate;
+    b.diag_prio = g_dbk_diag.prio;
+    b.diag_dummy = g_dbk_diag.dummy;
+    b.use_queue = g_dbk_diag.queue;
+    b.diag_xshift = (mode == 1 && g_dbk_diag.align) ? 4 * sample_bytes : 0;
+#else
+    if (mode != 0) return hipErrorInvalidValue; /* the copy diagnostic exists in libhevcdbk_diag.so only */
+#endif
     dim3 grid, block;
     const bool linear = plan_packed(a, b, grid, block);
     if (linear) {
@@ -1003,8 +1050,10 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
 /* all planes 8-bit, scalar QP, same frame count; plane 0 luma, the others chroma */
 bool dbk_multi_supports(const DbkArgs *planes, int n, const int *sample_bytes)
 {
-    static const bool off = [] { const char *e = getenv("HEVCDBK_TUNE"); return e && strstr(e, "nofuse") != nullptr; }();
-    if (off || n < 2 || n > 3) return false;
+#ifdef HEVCDBK_DIAG
+    if (g_dbk_diag.nofuse) return false;
+#endif
+    if (n < 2 || n > 3) return false;
     for (int i = 0; i < n; i++)
         if (sample_bytes[i] != 1 || planes[i].qp_map || planes[i].max_v != 255 || planes[i].n_frames != planes[0].n_frames ||
             planes[i].nbx > planes[0].nbx)
@@ -1025,7 +1074,7 @@ hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t str
         m.row_end[i] = rows;
     }
     if (rows <= 0 || planes[0].n_frames <= 0) return hipSuccess;
-    const int cap = tune_wg_cap();
+    const int cap = wg_cap();
     const int per_wg = planes[0].nbx < cap ? planes[0].nbx : cap;
     dim3 block((per_wg + 63) / 64 * 64, 1, 1);
     dim3 grid(rows, planes[0].n_frames, (planes[0].nbx + (int)block.x - 1) / (int)block.x);
@@ -1038,9 +1087,10 @@ bool dbk_packed_h265_supports(const DbkH265Args &h, int sample_bytes, bool chrom
 {
     const DbkArgs &a = h.base;
     if ((unsigned long long)a.pitch * (unsigned long long)a.plane_h >= (1ull << 31)) return false;
+    /* tc comes from Table 8-12 (<= 24), scaled to the bit depth: always inside the packed core's range, checked anyway */
+    if (!chroma && !dbk::packed_luma_tc_fits(a.max_v, 24 << a.shift)) return false;
     if (sample_bytes == 1) return a.max_v == 255;
     /* 16-bit containers up to 12 bit (12-bit luma: the WIDE variant), see deblock_packed16.h */
-    (void)chroma;
     return a.max_v <= 4095 && a.pitch % 8 == 0 && a.frame_stride % 8 == 0 &&
            ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0;
 }

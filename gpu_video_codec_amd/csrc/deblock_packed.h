@@ -123,6 +123,19 @@ struct Taps {
     pk p0, p1, p2, p3, q0, q1, q2, q3;
 };
 
+/* Operand range of the packed luma core: besides the samples (<= 11 bit plain, 12 bit WIDE) the largest tc a lane can
+ * see -- already scaled by 1 << (bit_depth - 8) -- must keep every 16-bit field in range.  The reference's tables stay far
+ * inside (tc <= 20 << 4); caller-supplied tables (hevcdbk_tables) can hold entries up to 255:
+ *   strong filter: the 5-tap sum carries the clip offset, 8*max_v + 4 + 8*(2*tc); it is shifted arithmetically
+ *                  (< 2^15) in the plain core and logically (< 2^16) in the WIDE one;
+ *   normal filter: the threshold 10*tc and (p2 + p0 + 1 - 2*p1) + 2*clip(delta, 2*tc) are signed 16-bit values.
+ * Outside this range the launcher takes the 32-bit kernel. */
+DBK_HD bool packed_luma_tc_fits(int max_v, int tc_max)
+{
+    const long long strong = 8ll * max_v + 4 + 16ll * tc_max;
+    return strong <= (max_v > 2047 ? 65535 : 32767) && 10ll * tc_max <= 32767 && 2ll * max_v + 1 + 4ll * tc_max <= 32767;
+}
+
 /* ---- unpack ------------------------------------------------------------------------------------ */
 
 /* vertical-edge segment (cpu.h:159-284): lines are rows ra (low half) and rb (high half);

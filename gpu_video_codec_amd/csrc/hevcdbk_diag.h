@@ -1,0 +1,35 @@
+/*
+ * hevcdbk_diag.h -- the DIAGNOSTIC build of the library (libhevcdbk_diag.so = the same sources compiled with
+ * -DHEVCDBK_DIAG).  It carries what must never ship: the copy variant of the packed kernels (their loads and stores with
+ * no arithmetic), the timing-only ablations of the luma filter (WRONG pixels), the measured-and-rejected LDS-queue kernel,
+ * launch-geometry knobs.  Tools under tools/ and the ablation tests load it; libhevcdbk.so has none of these symbols,
+ * none of these kernels, and reads no environment variable.
+ */
+#pragma once
+#include "../../include/hevc_deblock.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* kernel selector of hevc_deblocking_filter_device / hevcdbk_device_run_timed, diagnostic library only: the packed
+ * kernel's loads and stores with no arithmetic (dst = src) -- the memory-path ceiling of the access pattern */
+#define HEVCDBK_DIAG_KERNEL_COPY 100
+
+/* comma-separated knobs, process-wide, replacing the previous set (NULL or "" = defaults):
+ *   wg=N      workgroup width cap of the packed kernels (64..1024, default 512)
+ *   noswz     row-major map without the per-XCD workgroup renumbering
+ *   nofuse    Y, U, V as three launches even where the fused launch applies
+ *   dmacopy   small frames through DMA copies instead of host-direct kernels
+ *   queue     8-bit luma through the LDS-queue kernel (bit-exact, slower)
+ *   align     copy variant: row spans shifted onto their natural alignment
+ *   mode3     8-bit luma through the instrumented instantiation of the kernel with no knob active (A/B baseline)
+ *   prio=N    wave priority experiment: bit 0 = s_setprio 3 until the row loads are issued, bit 1 = from the final pack on
+ *   dummy=N   N extra VALU instructions per wave (how the kernel time responds to VALU work)
+ *   nostrong | nonormal | barriers   luma ablations -- WRONG PIXELS, timing only
+ * returns HEVCDBK_OK or HEVCDBK_ERR_ARG (unknown knob; nothing changed) */
+HEVCDBK_API int hevcdbk_diag_set(const char *spec);
+
+#ifdef __cplusplus
+}
+#endif

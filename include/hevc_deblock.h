@@ -179,8 +179,12 @@ typedef struct {
 #define HEVCDBK_KERNEL_AUTO    0 /* fastest kernel that supports the operands */
 #define HEVCDBK_KERNEL_GENERIC 1 /* one lane per offset block, 32-bit scalar arithmetic (all operand kinds) */
 #define HEVCDBK_KERNEL_PACKED  2 /* packed 16-bit arithmetic kernel (8-bit samples, scalar QP) */
-#define HEVCDBK_KERNEL_DIAG_COPY 100 /* diagnostic: the packed kernel's loads and stores with no arithmetic (dst = src);
-                                       measures the memory-path ceiling of the access pattern, not a filter */
+/* optional, OR-ed into the selector: how the packed kernels deal offset blocks to lanes.  Both maps produce the same
+ * bytes; AUTO picks per geometry from measurements. */
+#define HEVCDBK_MAP_AUTO   0x000
+#define HEVCDBK_MAP_ROWS   0x100 /* one workgroup per block row */
+#define HEVCDBK_MAP_LINEAR 0x200 /* row-major block numbering, workgroups renumbered per XCD */
+#define HEVCDBK_MAP_MASK   0x300
 
 HEVCDBK_API int hevc_deblocking_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes,
                                   unsigned qp, const hevcdbk_tables *tables, int kernel_variant,

@@ -96,7 +96,15 @@ private:
     void check(int rc)
     {
         if (rc == HEVCDBK_OK) return;
-        throw (rc == HEVCDBK_ERR_HIP && _ctx && hevcdbk_last_error(_ctx)[0]) ? hevcdbk_last_error(_ctx) : hevcdbk_strerror(rc);
+        /* The reference throws `const char *` (cpu.h:43-48), so this does too.  The HIP detail text lives in the context,
+         * which ~ReadYuvFrame destroys while the exception unwinds: copy it into storage that outlives the object (one
+         * buffer per thread) before throwing; hevcdbk_strerror() strings are static. */
+        if (rc == HEVCDBK_ERR_HIP && _ctx && hevcdbk_last_error(_ctx)[0]) {
+            static thread_local char detail[512];
+            std::snprintf(detail, sizeof(detail), "%s", hevcdbk_last_error(_ctx));
+            throw static_cast<const char *>(detail);
+        }
+        throw hevcdbk_strerror(rc);
     }
     unsigned int _width, _height, _Qp;
     hevcdbk_context *_ctx;

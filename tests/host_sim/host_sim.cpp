@@ -119,6 +119,16 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
 }
 
 extern "C" int host_sim_have_packed(void) { return HAVE_PACKED; }
+/* the launcher's operand-range predicate for the packed luma core (deblock_packed.h) */
+extern "C" int host_sim_packed_luma_tc_fits(int max_v, int tc_max)
+{
+#if HAVE_PACKED
+    return dbk::packed_luma_tc_fits(max_v, tc_max) ? 1 : 0;
+#else
+    (void)max_v; (void)tc_max;
+    return 0;
+#endif
+}
 
 extern "C" void host_sim_filter_plane(void *plane, int w, int h, long pitch_bytes, int sample_bytes, int is_chroma,
                                       const uint8_t *vbs, const uint8_t *hbs, int tc, int beta, int max_v,

@@ -51,6 +51,23 @@ def test_no_oracle_or_cpu_filter_in_product():
             assert "oracle" not in src.replace("the oracle", "").lower() or fn == "deblock.py" and "import oracle" not in src
 
 
+def test_product_library_reads_no_environment_and_has_no_diagnostics():
+    """The diagnostics (copy variant, timing-only ablations with WRONG pixels, the LDS-queue kernel, launch knobs) live in
+    libhevcdbk_diag.so only: the shipped library does not import getenv, carries none of the knob names or diagnostic
+    kernels, and does not export the knob setter."""
+    import subprocess
+    from gpu_video_codec_amd import _lib
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH]).decode()
+    assert "getenv" not in und
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for needle in (b"HEVCDBK_TUNE", b"HEVCDBK_WG", b"dbk_packed_q_kernel", b"nostrong", b"hevcdbk_diag_set"):
+        assert needle not in blob, needle
+    assert os.path.exists(_lib.DIAG_LIB_PATH)
+    dsyms = subprocess.check_output(["nm", "-D", "--defined-only", _lib.DIAG_LIB_PATH]).decode()
+    assert "hevcdbk_diag_set" in dsyms
+    assert b"dbk_packed_q_kernel" in open(_lib.DIAG_LIB_PATH, "rb").read()
+
+
 def test_tables_and_bs_helpers_match_oracle(L, oracle):
     from gpu_video_codec_amd import deblock
     tc, beta = deblock.default_tables()

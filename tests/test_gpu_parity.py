@@ -2,11 +2,12 @@
 (libhevcdbk.so), against the oracle on the same seeded inputs and against the golden vectors the
 reference produced.  Bit-exact is the only accepted tolerance (8/16-bit integer samples)."""
 import os
+import sys
 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, sha256
+from conftest import GOLDEN, ROOT, sha256
 
 pytestmark = pytest.mark.gpu
 
@@ -228,6 +229,44 @@ def test_custom_tables(ctx, oracle, golden_inputs):
         assert np.array_equal(got[0], oracle.filter_plane(y, 33, tc_table=tc2, beta_table=beta2))
 
 
+def test_maximal_custom_tables_at_10_11_12_bit(ctx, oracle):
+    """Caller tables with entries up to 255 scale to tc values the packed core's 16-bit fields cannot hold at 11 and 12
+    bit (8*max_v + 4 + 16*tc, 10*tc): HEVCDBK_KERNEL_AUTO must then take the 32-bit kernel (same bytes as the oracle) and
+    an explicit HEVCDBK_KERNEL_PACKED must be refused; inside the range -- up to its very edge -- the packed kernel runs
+    and is bit-exact.  Scalar QP and QP map (the map case is bounded by the largest table entry)."""
+    from gpu_video_codec_amd import deblock, _lib
+    rng = np.random.default_rng(77)
+    for bd, entry, fits in ((8, 255, True), (10, 255, True), (11, 128, True), (11, 255, False), (12, 128, True), (12, 129, False),
+                            (12, 255, False)):
+        max_v, shift = (1 << bd) - 1, bd - 8
+        h, w = 72, 520
+        y = np.full((h, w), max_v // 2, np.int64)
+        y[:, : w // 4] += rng.integers(-3, 4, (h, w // 4)) << shift
+        y[:, w // 4: w // 2] = rng.integers(0, max_v + 1, (h, w // 4))
+        y[:, w // 2:] = np.where(rng.integers(0, 2, (h, w - w // 2)) > 0, max_v - rng.integers(0, 5, (h, w - w // 2)),
+                                 rng.integers(0, 5, (h, w - w // 2)))
+        y = y.clip(0, max_v).astype(np.uint8 if bd == 8 else np.uint16)
+        tct, bt = np.full(52, entry, np.uint8), np.full(52, 255, np.uint8)
+        want = oracle.filter_plane(y, 40, bit_depth=bd, tc_table=tct, beta_table=bt)
+        for variant in (_lib.KERNEL_AUTO, _lib.KERNEL_GENERIC):
+            got = run_batch(ctx, y[None], 40, variant=variant, bit_depth=bd, tc_table=tct, beta_table=bt)
+            assert np.array_equal(got[0], want), (bd, entry, variant)
+        if fits:
+            got = run_batch(ctx, y[None], 40, variant=_lib.KERNEL_PACKED, bit_depth=bd, tc_table=tct, beta_table=bt)
+            assert np.array_equal(got[0], want), (bd, entry, "packed")
+        else:
+            with pytest.raises(deblock.DeblockError) as e:
+                run_batch(ctx, y[None], 40, variant=_lib.KERNEL_PACKED, bit_depth=bd, tc_table=tct, beta_table=bt)
+            assert e.value.code == _lib.ERR_UNSUPPORTED
+        # QP map: a table whose entry AT THE MAP'S QPs is small but whose largest entry is out of range still goes 32-bit
+        tcm = np.full(52, 4, np.uint8)
+        tcm[51] = entry
+        qmap = np.full(((h + 63) // 64, (w + 63) // 64), 30, np.uint8)
+        wantm = oracle.filter_plane(y, 30, bit_depth=bd, tc_table=tcm, beta_table=bt, qp_map=qmap)
+        got = run_batch(ctx, y[None], 30, variant=_lib.KERNEL_AUTO, bit_depth=bd, tc_table=tcm, beta_table=bt, qp_map=qmap)
+        assert np.array_equal(got[0], wantm), (bd, entry, "map")
+
+
 # ---- properties at BASELINE's full sizes ------------------------------------------------------------
 
 def test_4k_batch_properties(ctx, oracle):
@@ -319,45 +358,91 @@ def test_error_codes_on_device(ctx, oracle):
     b.free()
 
 
-def test_row_major_mapping_forced(ctx, oracle, monkeypatch):
+def test_row_major_mapping_forced(ctx, oracle):
     """The row-major (linear) block mapping is chosen automatically only for rows wider than one
-    workgroup (8K); force it on small, ragged and multi-frame geometries as well."""
+    workgroup (8K); force it (HEVCDBK_MAP_LINEAR of the kernel selector) on small, ragged and multi-frame
+    geometries as well, and the row map (HEVCDBK_MAP_ROWS) on the same ones: same bytes."""
     from gpu_video_codec_amd import synth, _lib
-    monkeypatch.setenv("HEVCDBK_TUNE", "linear")
     rng = np.random.default_rng(99)
-    for (w, h) in [(352, 288), (520, 136), (1032, 72), (3840, 64), (4104, 40)]:
-        frames = np.stack([synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30))) for _ in range(3)])
-        frames[1, : h // 2, : w // 3] = rng.integers(0, 256, (h // 2, w // 3), dtype=np.uint8)
-        bss = [oracle.lcg_bs(w, h, 5), oracle.default_bs(w, h), oracle.lcg_bs(w, h, 6)]
-        got = run_batch(ctx, frames, 37, variant=_lib.KERNEL_PACKED, bs=bss)
-        for f in range(3):
-            assert np.array_equal(got[f], oracle.filter_plane(frames[f], 37, vert_bs=bss[f][0], hor_bs=bss[f][1])), (w, h, f)
-        f10 = np.stack([synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30)), bit_depth=10) for _ in range(2)])
-        got = run_batch(ctx, f10, 32, variant=_lib.KERNEL_PACKED, bit_depth=10)
-        for f in range(2):
-            assert np.array_equal(got[f], oracle.filter_plane(f10[f], 32, bit_depth=10)), (w, h, f)
-        c = frames[:2]
-        got = run_batch(ctx, c, 40, variant=_lib.KERNEL_PACKED, is_chroma=True)
-        for f in range(2):
-            assert np.array_equal(got[f], oracle.filter_plane(c[f], 40, is_chroma=True)), (w, h, f)
+    for mapping in (_lib.MAP_LINEAR, _lib.MAP_ROWS):
+        variant = _lib.KERNEL_PACKED | mapping
+        for (w, h) in [(352, 288), (520, 136), (1032, 72), (3840, 64), (4104, 40)]:
+            frames = np.stack([synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30))) for _ in range(3)])
+            frames[1, : h // 2, : w // 3] = rng.integers(0, 256, (h // 2, w // 3), dtype=np.uint8)
+            bss = [oracle.lcg_bs(w, h, 5), oracle.default_bs(w, h), oracle.lcg_bs(w, h, 6)]
+            got = run_batch(ctx, frames, 37, variant=variant, bs=bss)
+            for f in range(3):
+                assert np.array_equal(got[f], oracle.filter_plane(frames[f], 37, vert_bs=bss[f][0], hor_bs=bss[f][1])), (w, h, f)
+            f10 = np.stack([synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30)), bit_depth=10) for _ in range(2)])
+            got = run_batch(ctx, f10, 32, variant=variant, bit_depth=10)
+            for f in range(2):
+                assert np.array_equal(got[f], oracle.filter_plane(f10[f], 32, bit_depth=10)), (w, h, f)
+            c = frames[:2]
+            got = run_batch(ctx, c, 40, variant=variant, is_chroma=True)
+            for f in range(2):
+                assert np.array_equal(got[f], oracle.filter_plane(c[f], 40, is_chroma=True)), (w, h, f)
+    # an unknown map selector is refused, not ignored
+    from gpu_video_codec_amd import deblock
+    b = deblock.DeviceBatch(ctx, 64, 64, 1)
+    with pytest.raises(deblock.DeblockError) as e:
+        ctx.filter_device(b.planes(), 30, variant=_lib.KERNEL_PACKED | 0x300)
+    assert e.value.code == _lib.ERR_ARG
+    b.free()
 
 
-def test_lds_queue_variant_is_bit_exact(ctx, oracle, monkeypatch):
-    """HEVCDBK_TUNE=queue selects the experimental 8-bit luma kernel that schedules strong segments through
-    a workgroup LDS queue: same bytes, including queue overflow (an all-flat frame makes every
-    segment strong) and planes narrower than a workgroup."""
-    from gpu_video_codec_amd import synth, _lib
-    monkeypatch.setenv("HEVCDBK_TUNE", "queue")
-    flat = np.full((96, 4096), 100, np.uint8)
-    flat[:, 2048:] += 4          # mild steps on every 8x8 edge: strong filter everywhere -> queue overflows
-    flat[::16] += 2
-    frames = {"synth": synth.blocky_plane(3840, 72, seed=8), "flat": flat,
-              "narrow": synth.blocky_plane(200, 64, seed=9), "noise": np.random.default_rng(1).integers(0, 256, (64, 1032), dtype=np.uint8)}
+_DIAG_CHILD = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from gpu_video_codec_amd import _lib, deblock, synth
+from oracle import oracle
+_lib.use_diagnostic_library(%(spec)r)
+sys.path.insert(0, %(tests)r)
+from test_gpu_parity import run_batch
+flat = np.full((96, 4096), 100, np.uint8)
+flat[:, 2048:] += 4          # mild steps on every 8x8 edge: strong filter everywhere -> the queue overflows
+flat[::16] += 2
+frames = {"synth": synth.blocky_plane(3840, 72, seed=8), "flat": flat,
+          "narrow": synth.blocky_plane(200, 64, seed=9), "noise": np.random.default_rng(1).integers(0, 256, (64, 1032), dtype=np.uint8)}
+with deblock.Context(0) as ctx:
     for name, y in frames.items():
         for qp in (32, 45):
             got = run_batch(ctx, np.stack([y, y[::-1]]), qp, variant=_lib.KERNEL_PACKED)
             assert np.array_equal(got[0], oracle.filter_plane(y, qp)), (name, qp)
             assert np.array_equal(got[1], oracle.filter_plane(y[::-1], qp)), (name, qp)
+    # the copy variant exists here (and only here): dst = src
+    y = frames["synth"]
+    got = run_batch(ctx, np.stack([y]), 32, variant=_lib.DIAG_KERNEL_COPY)
+    assert np.array_equal(got[0], y)
+print("DIAG-OK")
+"""
+
+
+def _run_diag_child(spec):
+    import subprocess
+    code = _DIAG_CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "spec": spec}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIAG-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_diagnostic_library_variants_are_bit_exact():
+    """libhevcdbk_diag.so (same sources, -DHEVCDBK_DIAG) in a process of its own: the LDS-queue kernel (knob "queue":
+    strong segments scheduled through a workgroup queue) gives the same bytes, including queue overflow
+    (an all-flat frame makes every segment strong) and planes narrower than a workgroup; so do the instrumented
+    instantiation with its knobs at rest, other workgroup widths and the wave-priority experiment."""
+    _run_diag_child("queue")
+    _run_diag_child("mode3,wg=256,prio=3")
+
+
+def test_product_library_has_no_diagnostics(ctx):
+    """The shipped library refuses the copy selector and exports no diagnostic entry point."""
+    from gpu_video_codec_amd import deblock, _lib
+    assert not hasattr(_lib.lib(), "hevcdbk_diag_set")
+    b = deblock.DeviceBatch(ctx, 64, 64, 1)
+    with pytest.raises(deblock.DeblockError) as e:
+        ctx.filter_device(b.planes(), 30, variant=_lib.DIAG_KERNEL_COPY)
+    assert e.value.code == _lib.ERR_ARG
+    b.free()
 
 
 def test_pitched_planes_and_untouched_row_padding(ctx, oracle):

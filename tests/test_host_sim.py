@@ -21,10 +21,15 @@ def sim():
     return L
 
 
-def run_sim(sim, oracle, plane, qp, *, is_chroma=False, bit_depth=8, vbs=None, hbs=None, qp_map=None, packed=0):
+def run_sim(sim, oracle, plane, qp, *, is_chroma=False, bit_depth=8, vbs=None, hbs=None, qp_map=None, packed=0,
+            tc_table=None, beta_table=None):
     out = np.ascontiguousarray(plane).copy()
     h, w = out.shape
     tc_t, beta_t = oracle.tables()
+    if tc_table is not None:
+        tc_t = np.asarray(tc_table)
+    if beta_table is not None:
+        beta_t = np.asarray(beta_table)
     dv, dh = oracle.default_bs(w, h)
     vbs = dv if vbs is None else np.ascontiguousarray(vbs, np.uint8)
     hbs = dh if hbs is None else np.ascontiguousarray(hbs, np.uint8)
@@ -167,3 +172,33 @@ def test_packed_with_ctu_qp_map(sim, oracle):
         y10 = synth.blocky_plane(768, 576, seed=7, bit_depth=10)
         assert np.array_equal(run_sim(sim, oracle, y10, 0, qp_map=qmap, bit_depth=10, packed=1),
                               oracle.filter_plane(y10, 0, qp_map=qmap, bit_depth=10)), (lo, hi)
+
+
+def test_packed_core_operand_range_with_maximal_custom_tables(sim, oracle):
+    """Caller-supplied tc / beta tables (hevcdbk_tables) may hold entries up to 255, scaled by 1 << (bit_depth - 8): the
+    launcher hands a plane to the packed luma core only while packed_luma_tc_fits() holds.  Inside that range -- including
+    exactly at its edge -- the packed arithmetic must equal the oracle; the first value beyond it must be refused (and is
+    known to overflow the 16-bit fields)."""
+    if not sim.host_sim_have_packed():
+        pytest.skip("packed core not compiled into the host sim")
+    rng = np.random.default_rng(2024)
+    for bd, edge in ((8, 255), (10, 255), (11, 128), (12, 128)):
+        max_v, shift = (1 << bd) - 1, bd - 8
+        assert sim.host_sim_packed_luma_tc_fits(max_v, edge << shift) == 1, bd
+        if edge < 255:
+            assert sim.host_sim_packed_luma_tc_fits(max_v, (edge + 1) << shift) == 0, bd
+        h, w = 64, 256
+        # flat areas with small steps (strong filter), ramps (normal filter) and full-range noise (clipping at 0 / max_v)
+        y = np.full((h, w), max_v // 2, np.int64)
+        y[:, : w // 4] += rng.integers(-3, 4, (h, w // 4)) << shift
+        y[:, w // 4: w // 2] = rng.integers(0, max_v + 1, (h, w // 4))
+        y[:, w // 2: 3 * w // 4] = (np.arange(w // 4)[None, :] * (max_v // 80) + rng.integers(0, 2 << shift, (h, w // 4))) % (max_v + 1)
+        y[:, 3 * w // 4:] = np.where(rng.integers(0, 2, (h, w // 4)) > 0, max_v - rng.integers(0, 5, (h, w // 4)), rng.integers(0, 5, (h, w // 4)))
+        y = y.clip(0, max_v).astype(np.uint8 if bd == 8 else np.uint16)
+        tct = np.full(52, edge, np.uint8)
+        bt = np.full(52, 255, np.uint8)
+        for qp in (20, 51):
+            want = oracle.filter_plane(y, qp, bit_depth=bd, tc_table=tct, beta_table=bt)
+            for packed in (0, 1):
+                got = run_sim(sim, oracle, y, qp, bit_depth=bd, packed=packed, tc_table=tct, beta_table=bt)
+                assert np.array_equal(got, want), (bd, qp, packed)

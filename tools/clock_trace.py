@@ -7,7 +7,10 @@ from gpu_video_codec_amd import _lib, deblock
 import bench
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-variant = {"packed": _lib.KERNEL_PACKED, "copy": _lib.KERNEL_DIAG_COPY}[sys.argv[2] if len(sys.argv) > 2 else "packed"]
+which = sys.argv[2] if len(sys.argv) > 2 else "packed"
+if which == "copy":
+    _lib.use_diagnostic_library()
+variant = {"packed": _lib.KERNEL_PACKED, "copy": _lib.DIAG_KERNEL_COPY}[which]
 ctx = deblock.Context(0)
 frames = bench.make_frames(3840, 2160, 64, 8)
 b = deblock.DeviceBatch(ctx, 3840, 2160, 64)

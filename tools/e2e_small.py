@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Host-frame operator on a small 4:2:0 frame (the reference's own CPU-runnable case, configs[0]): median of the
-reference's timing triple over repeated calls.  HEVCDBK_TUNE=nofuse gives the three-launch form for comparison."""
+reference's timing triple over repeated calls.  --diag nofuse (libhevcdbk_diag.so) gives the three-launch form for comparison."""
 import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gpu_video_codec_amd import deblock, synth
+from gpu_video_codec_amd import _lib, deblock, synth
 
 
 def main():
@@ -13,9 +13,12 @@ def main():
     ap.add_argument("--height", type=int, default=288)
     ap.add_argument("--qp", type=int, default=35)
     ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--diag", default=None, help="run on libhevcdbk_diag.so with these knobs (nofuse, dmacopy, ...): A/B runs only")
     ap.add_argument("--file-frames", type=int, default=0, help="also time hevcdbk_filter_yuv_file on a file of N frames")
     ap.add_argument("--sequence-frames", type=int, default=0, help="also time hevc_deblocking_filter_sequence on N frames")
     a = ap.parse_args()
+    if a.diag is not None:
+        _lib.use_diagnostic_library(a.diag)
     ctx = deblock.Context(0)
     if a.sequence_frames:
         base = [synth.blocky_yuv420(a.width, a.height, seed=11, frame=i) for i in range(8)]
@@ -79,7 +82,7 @@ def main():
         rows.append(tm)
     rows = rows[len(rows) // 4:]
     med = {k: float(np.median([r[k] for r in rows])) for k in rows[0]}
-    med.update(width=a.width, height=a.height, tune=os.environ.get("HEVCDBK_TUNE", ""))
+    med.update(width=a.width, height=a.height, diag=a.diag or "")
     print(json.dumps(med))
 
 
