@@ -12,6 +12,14 @@ processes, never an exec).  Frames shard frame-parallel with NO data-path collec
 torch.distributed (gloo) is used only for the barrier and the max-over-ranks of the elapsed time.
 Scaling is weak: every rank filters its own F frames.
 
+After the headline measurement, rank 0 of a one-GPU run adds (each with its own bit-exactness spot check):
+  extra_configs   the same kernel at 64 frames per launch (a decoder-sized batch), BASELINE config 4 as whole
+                  4:2:0 frames (Y + U + V) and config 5 (7680x4320 10-bit luma), with ms_per_step / frac / bytes;
+  cpu_baseline    the reference's thread ladder (main.cu:36-83: 1, 2, 4, 6, 8 threads, plus all host cores):
+                  >= 30 repetitions each, min and median, filter-only window (main.cu:41-43);
+  reference_table the reference README's own line (README.md:19-24): 352x288 QP 35 Y+U+V, CPU 1T, CPU OpenMP,
+                  GPU exec / total / copy in seconds.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -47,32 +55,44 @@ def make_frames(w, h, n, bit_depth, seed=1, n_base=4):
     return out
 
 
-def cpu_baseline(frames, qp, bit_depth, budget_s, threads_all):
-    """Times the CPU checker (oracle 'port', luma only) on a bounded sample of the same frames:
-    single thread (the parity target) and OpenMP on all host cores, one warm-up each."""
+def cpu_ladder(frames, qp, bit_depth, threads_all, reps=30, budget_s=40.0):
+    """The reference's timing ladder (main.cu:36-83 runs ExecuteCpu at 1, 2, 4, 6, 8 OpenMP threads) on the CPU
+    checker (oracle 'port', luma only, same frames as the GPU batch), plus all host cores: one warm-up call per
+    thread count (cold OpenMP team start-up costs 20-200 ms), then >= `reps` repetitions, min and median of the
+    filter-only window (main.cu:41-43; the frame constructor is untimed like main.cu:40)."""
     from oracle import oracle
-    res = {}
-    for label, nt in (("t1", 1), ("omp", threads_all)):
-        oracle.filter_plane(frames[0], qp, bit_depth=bit_depth, threads=nt)  # warm-up (OpenMP team start)
-        n, t0 = 0, time.perf_counter()
+    ladder = []
+    t_start = time.perf_counter()
+    counts = [1, 2, 4, 6, 8] + ([threads_all] if threads_all not in (1, 2, 4, 6, 8) else [])
+    for nt in counts:
+        oracle.filter_plane(frames[0], qp, bit_depth=bit_depth, threads=nt)  # warm-up
         times = []
-        while True:
-            f = frames[n % len(frames)]
-            fr = oracle.Frame(f, bit_depth=bit_depth)     # ctor untimed, like main.cu:40
+        for n in range(reps):
+            fr = oracle.Frame(frames[n % len(frames)], bit_depth=bit_depth)
             a = time.perf_counter()
-            fr.filter(qp, planes=oracle.PLANE_Y, threads=nt)  # window = filter only (main.cu:41-43)
+            fr.filter(qp, planes=oracle.PLANE_Y, threads=nt)
             times.append(time.perf_counter() - a)
             fr.close()
-            n += 1
-            if time.perf_counter() - t0 > budget_s / 2 or n >= 400:
+            if time.perf_counter() - t_start > budget_s and len(times) >= 5:
                 break
-        res[label] = {"threads": nt, "frames": n, "min_s": min(times), "median_s": float(np.median(times))}
-    out = {"value": 1.0 / res["t1"]["median_s"], "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d luma frames 1T + %d frames OpenMP(%d) of the benchmark batch, filter-only window, median"
-                     % (res["t1"]["frames"], res["omp"]["frames"], threads_all),
-           "t1_min_s": res["t1"]["min_s"], "t1_median_s": res["t1"]["median_s"],
-           "omp_threads": threads_all, "omp_value": 1.0 / res["omp"]["median_s"],
-           "omp_min_s": res["omp"]["min_s"], "omp_median_s": res["omp"]["median_s"]}
+        ladder.append({"threads": nt, "reps": len(times), "min_s": min(times), "median_s": float(np.median(times)),
+                       "frames_per_s": 1.0 / float(np.median(times))})
+    return ladder
+
+
+def cpu_baseline(frames, qp, bit_depth, threads_all):
+    from oracle import oracle
+    ladder = cpu_ladder(frames, qp, bit_depth, threads_all)
+    t1 = ladder[0]
+    best = max(ladder, key=lambda r: r["frames_per_s"])
+    out = {"value": t1["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d luma frames of the benchmark batch per thread count (1/2/4/6/8/all = the reference's ladder, "
+                     "main.cu:36-83), filter-only window, median of >= %d repetitions after one warm-up"
+                     % (len(frames), min(r["reps"] for r in ladder)),
+           "t1_min_s": t1["min_s"], "t1_median_s": t1["median_s"],
+           "omp_threads": best["threads"], "omp_value": best["frames_per_s"],
+           "omp_min_s": best["min_s"], "omp_median_s": best["median_s"],
+           "thread_ladder": ladder}
     # the reference's own code (Y+U+V of a 4:2:0 frame; it cannot filter luma alone), when oracle/_ref travelled
     try:
         if oracle.have_ref() and bit_depth == 8:
@@ -89,6 +109,70 @@ def cpu_baseline(frames, qp, bit_depth, budget_s, threads_all):
             out["reference_yuv420_1t_median_s"] = float(np.median(ts[1:]))
     except Exception as e:  # the reference build is optional evidence, never fatal
         out["reference_error"] = str(e)
+    return out
+
+
+def reference_table_line(ctx, threads_all, reps=30):
+    """The one timing table the reference publishes (README.md:19-24; main.cu:128-138 at this snapshot: mother-daughter
+    352x288, QP 35, Y+U+V), in its own units (seconds per frame): CPU single thread, CPU OpenMP, GPU execution time
+    without copy / with copy / copy only (gpu.cu:1292,1302-1303).  CPU = the checker; when oracle/_ref travelled, the
+    reference's own header too."""
+    from oracle import oracle
+    w, h, qp = 352, 288, 35
+    path = os.path.join(ROOT, "tests", "golden", "mother-daughter_352x288_yv12.yuv")
+    if os.path.exists(path):
+        with open(path, "rb") as fh:
+            buf = fh.read()
+        src = "tests/golden/mother-daughter_352x288_yv12.yuv (the reference's bundled input)"
+    else:
+        buf = oracle.join_yuv420(*synth.blocky_yuv420(w, h, seed=3))
+        src = "synthetic 352x288 4:2:0"
+    y, u, v = oracle.split_yuv420(buf, w, h)
+    want = oracle.filter_yuv420(buf, w, h, qp)
+
+    def cpu_times(nt):
+        fr0 = oracle.Frame(y, u, v)
+        fr0.filter(qp, threads=nt)  # warm-up
+        fr0.close()
+        ts = []
+        for _ in range(reps):
+            fr = oracle.Frame(y, u, v)
+            a = time.perf_counter()
+            fr.filter(qp, threads=nt)
+            ts.append(time.perf_counter() - a)
+            fr.close()
+        return {"threads": nt, "min_s": min(ts), "median_s": float(np.median(ts))}
+
+    nt_omp = min(8, threads_all)
+    out = {"input": src, "width": w, "height": h, "qp": qp, "planes": "Y+U+V",
+           "cpu_port_1t": cpu_times(1), "cpu_port_omp": cpu_times(nt_omp)}
+    try:
+        if oracle.have_ref():
+            for label, nt in (("cpu_reference_1t", 1), ("cpu_reference_omp", nt_omp)):
+                ts = []
+                for i in range(reps + 1):
+                    rf = oracle.RefFrame(buf, w, h, qp)
+                    a = time.perf_counter()
+                    rf.filter(nt)
+                    ts.append(time.perf_counter() - a)
+                    rf.close()
+                out[label] = {"threads": nt, "min_s": min(ts[1:]), "median_s": float(np.median(ts[1:]))}
+    except Exception as e:
+        out["reference_error"] = str(e)
+    rows = []
+    for i in range(60):
+        yy, uu, vv = y.copy(), u.copy(), v.copy()
+        a = time.perf_counter()
+        tm = ctx.filter_frame(yy, uu, vv, qp=qp)
+        tm["wall_s"] = time.perf_counter() - a
+        rows.append(tm)
+    rows = rows[10:]
+    out["gpu"] = {k: float(np.median([r[k] for r in rows])) for k in ("exec_s", "total_s", "copy_s", "wall_s")}
+    out["gpu"]["note"] = ("frames <= 2 MiB are not copied: the fused Y+U+V kernel reads and writes page-locked host memory "
+                          "across PCIe itself, so copy_s = 0 and exec_s contains the PCIe traffic (DESIGN.md 5)")
+    out["gpu_bit_exact"] = bool(oracle.join_yuv420(yy, uu, vv) == want)
+    out["reference_readme"] = {"cpu_1t_s": 0.0039335, "cpu_omp_s": 0.0019126, "gpu_exec_s": 0.0001362, "gpu_total_s": 0.0008509,
+                               "gpu_copy_s": 0.0007147, "hardware": "GTX 1060 Max-Q + its host CPU (README.md:23-24)"}
     return out
 
 
@@ -120,6 +204,83 @@ def host_threads():
     return max(1, min(n, 16))
 
 
+def roofline_of(kernel_ms, abytes):
+    kavg_ms = float(np.mean(kernel_ms))
+    achieved = abytes / (kavg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "kernel_avg_ms": kavg_ms, "kernel_min_ms": float(np.min(kernel_ms)), "algorithmic_bytes_per_launch": abytes}
+
+
+def extra_configs(ctx, args, frames, batch, variant):
+    """Measured after the headline, same settle / warm-up discipline, fewer steps; each with a spot check against the
+    oracle.  Never `value`."""
+    from oracle import oracle
+    out = {}
+    w, h, F, bd, qp = args.width, args.height, args.frames, args.bit_depth, args.qp
+    sb = 1 if bd == 8 else 2
+    settle, steps = max(args.settle // 2, 10), max(min(args.steps, 60), 10)
+
+    # (1) the headline kernel at a decoder-sized batch: 64 frames per launch
+    if F > 64:
+        p = batch.planes()
+        p.n_frames = 64
+        ctx.run_timed([p], qp, settle, variant=variant)
+        ms = ctx.run_timed([p], qp, steps, variant=variant)
+        r = roofline_of(ms, algorithmic_bytes_per_frame(w, h, sb) * 64)
+        out["luma_64_frames_per_launch"] = {
+            "workload": "%dx%d %d-bit luma, 64 frames per launch (same kernel, decoder-sized batch)" % (w, h, bd),
+            "ms_per_step": r["kernel_avg_ms"], "luma_frames_per_s": 64 / (r["kernel_avg_ms"] * 1e-3), "frac": r["frac"],
+            "achieved_GBps": r["achieved"], "algorithmic_bytes": r["algorithmic_bytes_per_launch"], "steps": steps}
+
+    # (2) BASELINE config 4 as whole 4:2:0 frames: Y + U + V of every frame per step
+    if bd == 8:
+        Fc = min(F, 128)
+        cw, ch = w // 2, h // 2
+        cb = []
+        for i in range(2):
+            b = deblock.DeviceBatch(ctx, cw, ch, Fc, bit_depth=bd, is_chroma=True, per_frame_bs=False)
+            src = np.stack([synth.blocky_plane(cw, ch, seed=31 + i, frame=f, bit_depth=bd, dc_range=4) for f in range(4)])
+            b.upload_all(np.concatenate([src] * (Fc // 4 + 1))[:Fc])
+            cb.append((b, src))
+        py = batch.planes()
+        py.n_frames = Fc
+        pl = [py, cb[0][0].planes(), cb[1][0].planes()]
+        ctx.run_timed(pl, qp, settle, variant=variant)
+        ms = ctx.run_timed(pl, qp, steps, variant=variant)
+        abytes = Fc * (algorithmic_bytes_per_frame(w, h, sb) + 2 * algorithmic_bytes_per_frame(cw, ch, sb))
+        r = roofline_of(ms, abytes)
+        ok = bool(np.array_equal(batch.download_frame(Fc - 1), oracle.filter_plane(frames[Fc - 1], qp, threads=8)))
+        for b, src in cb:
+            ok &= bool(np.array_equal(b.download_frame(1), oracle.filter_plane(src[1], qp, is_chroma=True)))
+        out["config4_yuv420"] = {
+            "workload": "%dx%d 8-bit 4:2:0 (Y+U+V), %d frames per step, QP %d, default bS, device-resident" % (w, h, Fc, qp),
+            "ms_per_step": r["kernel_avg_ms"], "yuv420_frames_per_s": Fc / (r["kernel_avg_ms"] * 1e-3), "frac": r["frac"],
+            "achieved_GBps": r["achieved"], "algorithmic_bytes": abytes, "steps": steps, "bit_exact_vs_oracle": ok}
+        for b, _ in cb:
+            b.free()
+
+    # (3) BASELINE config 5: 7680x4320 10-bit luma in 16-bit containers
+    if not args.no_config5:
+        w5, h5, F5, bd5 = 7680, 4320, 32, 10
+        f5 = make_frames(w5, h5, F5, bd5, seed=5, n_base=2)
+        b5 = deblock.DeviceBatch(ctx, w5, h5, F5, bit_depth=bd5)
+        b5.upload_all(f5)
+        p5 = b5.planes()
+        ctx.run_timed([p5], qp, settle, variant=variant)
+        ms = ctx.run_timed([p5], qp, steps, variant=variant)
+        abytes = F5 * algorithmic_bytes_per_frame(w5, h5, 2)
+        r = roofline_of(ms, abytes)
+        ok = bool(np.array_equal(b5.download_frame(F5 - 1), oracle.filter_plane(f5[F5 - 1], qp, bit_depth=bd5, threads=8)))
+        out["config5_8k_10bit"] = {
+            "workload": "%dx%d %d-bit luma (16-bit containers), %d frames per launch, QP %d, default bS" % (w5, h5, bd5, F5, qp),
+            "ms_per_step": r["kernel_avg_ms"], "luma_frames_per_s": F5 / (r["kernel_avg_ms"] * 1e-3), "frac": r["frac"],
+            "achieved_GBps": r["achieved"], "algorithmic_bytes": abytes, "steps": steps, "bit_exact_vs_oracle": ok,
+            "parity": "unpinned beyond 8 bit (the reference is 8-bit only, SURVEY 8c): checked against the CPU restatement"}
+        b5.free()
+        del f5
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,9 +303,10 @@ def main():
                     help="block -> lane map of the packed kernels (HEVCDBK_MAP_*; same bytes either way)")
     ap.add_argument("--diag", default=None,
                     help="load libhevcdbk_diag.so and set these knobs (csrc/hevcdbk_diag.h): A/B runs only, never a result")
-    ap.add_argument("--cpu-budget-s", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and the reference table line")
+    ap.add_argument("--no-config5", action="store_true", help="skip the 8K 10-bit extra config (3.2 GB of host frames)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -205,16 +367,17 @@ def main():
     from oracle import oracle
     bit_exact = True
     for f in sorted({0, F // 2, F - 1}):
-        want = frames[f] if args.variant == "copy" else oracle.filter_plane(frames[f], args.qp, bit_depth=bd)
+        want = frames[f] if args.variant == "copy" else oracle.filter_plane(frames[f], args.qp, bit_depth=bd, threads=8)
         bit_exact &= bool(np.array_equal(batch.download_frame(f), want))
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * F * args.steps / elapsed
     abytes = algorithmic_bytes_per_frame(w, h, sb) * F
-    kavg_ms = float(np.mean(kernel_ms))
-    achieved = abytes / (kavg_ms * 1e-3) / 1e9
-
+    roof = roofline_of(kernel_ms, abytes)
     traffic = measured_traffic(w, h, F, bd) if args.variant in ("auto", "packed") else None
+    roof["traffic"] = traffic[0] if traffic else None
+    roof["traffic_source"] = traffic[1] if traffic else None
+    roof["read_GBps"] = (abytes - w * h * sb * F) / (roof["kernel_avg_ms"] * 1e-3) / 1e9
     out = {
         "metric": "luma_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -225,14 +388,11 @@ def main():
                    "frames_per_gpu": F, "kernel_variant": args.variant, "block_map": args.map, "diag": args.diag,
                    "settle_launches": args.settle, "parallelism": "frame-parallel x%d, no collective" % world},
         "bit_exact_vs_oracle": bit_exact, "diagnostic_copy_only": args.variant == "copy",
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic[0] if traffic else None,
-                     "traffic_source": traffic[1] if traffic else None,
-                     "kernel_avg_ms": kavg_ms, "kernel_min_ms": float(np.min(kernel_ms)),
-                     "algorithmic_bytes_per_launch": abytes,
-                     "read_GBps": (abytes - w * h * sb * F) / (kavg_ms * 1e-3) / 1e9},
+        "roofline": roof,
     }
-    if rank == 0 and world == 1 and args.variant != "copy":
+    if rank == 0 and world == 1 and args.variant != "copy" and args.diag is None:
+        if not args.no_extra:
+            out["extra_configs"] = extra_configs(ctx, args, frames, batch, variant)
         if not args.no_e2e:
             # end-to-end (PCIe-inclusive) rate of the host-frame operator; never `value`
             yy = frames[0].copy()
@@ -254,14 +414,16 @@ def main():
             for i, p in enumerate(pinned):
                 p[:] = frames[i]
             t_seq = ctx.filter_sequence([(p,) for p in pinned], qp=args.qp, bit_depth=bd)
-            seq_ok = all(np.array_equal(pinned[i], oracle.filter_plane(frames[i], args.qp, bit_depth=bd)) for i in (0, ns - 1))
+            seq_ok = all(np.array_equal(pinned[i], oracle.filter_plane(frames[i], args.qp, bit_depth=bd, threads=8)) for i in (0, ns - 1))
             out["e2e_host_frame"].update({"sequence_frames": ns, "sequence_frames_per_s": ns / t_seq,
                                           "sequence_pcie_GBps": 2 * w * h * sb * ns / t_seq / 1e9,
                                           "sequence_bit_exact": bool(seq_ok)})
             for p in pinned:
                 ctx.free_pinned(p)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames[: min(F, 8)], args.qp, bd, args.cpu_budget_s, host_threads())
+            out["cpu_baseline"] = cpu_baseline(frames[: min(F, 8)], args.qp, bd, host_threads())
+            if not args.no_extra and bd == 8:
+                out["reference_table_352x288"] = reference_table_line(ctx, host_threads())
     batch.free()
     ctx.close()
     if dist is not None:
@@ -269,7 +431,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if not bit_exact:
+    extras_ok = all(v.get("bit_exact_vs_oracle", True) for v in out.get("extra_configs", {}).values())
+    if not bit_exact or not extras_ok:
         raise SystemExit("bench: HIP output differs from the oracle")
 
 

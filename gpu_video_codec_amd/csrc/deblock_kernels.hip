@@ -734,7 +734,7 @@ __device__ __forceinline__ void q_stage(dbk::Taps (&A)[NS], dbk::Taps (&B)[NS], 
             const dbk::Decision d = dbk::decide(A[s], beta, tc);
             if (d.filter) {
                 if (d.strong) strong[s] = true;
-                else dbk::normal_pairs(A[s], B[s], tc, dbk::splat(d.cond5 ? -1 : 0), dbk::splat(d.cond6 ? -1 : 0), 255);
+                else dbk::normal_pairs(A[s], B[s], tc, dbk::mask_of(d.cond5), dbk::mask_of(d.cond6), 255);
             }
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(strong[s]);

@@ -38,6 +38,11 @@ typedef short pk __attribute__((vector_size(4))); /* two int16 lanes in one VGPR
 DBK_HD uint32_t pk_bits(pk a) { return __builtin_bit_cast(uint32_t, a); }
 DBK_HD pk bits_pk(uint32_t a) { return __builtin_bit_cast(pk, a); }
 DBK_HD pk splat(int v) { return pk{(short)v, (short)v}; }
+/* the same value in both halves, built with 32-bit integer operations: for a wave-uniform v (scalar QP) the compiler keeps
+ * all of it on the scalar unit and hands the packed constant to the VALU instruction as an SGPR operand */
+DBK_HD pk splat_u(int v) { const uint32_t x = (uint32_t)v & 0xffffu; return bits_pk(x | (x << 16)); }
+/* all-ones / all-zeros in both halves from a lane condition: one v_cndmask, no re-packing */
+DBK_HD pk mask_of(bool c) { return bits_pk(c ? 0xffffffffu : 0u); }
 
 DBK_HD pk pk_max(pk a, pk b)
 {
@@ -238,48 +243,106 @@ DBK_HD void strong_pair(Taps &t, pk c)
     t.q0 = nq0; t.q1 = nq1; t.q2 = nq2;
 }
 
-/* normal filter (cpu.h:1251-1354) up to, but not including, the final Clip2 to [0, max_v];
- * m5 / m6 = all-ones halves where cond5 / cond6 hold */
-template <bool WIDE = false>
-DBK_HD void normal_pair_unclipped(Taps &t, int tc, pk m5, pk m6)
+/* operands of the normal filter that depend on tc only (cpu.h:1233-1236, 1254): built once per segment */
+struct NormalK {
+    pk c, negc;   /* 2*tc and its negation */
+    pk c2, negc2; /* tc/2 */
+    pk lim;       /* 10*tc */
+};
+DBK_HD NormalK normal_k(int tc)
 {
-    const pk c = splat(2 * tc), c2 = splat(tc >> 1), lim = splat(10 * tc);
-    const pk zero = splat(0);
-    /* (9(q0-p0) - 3(q1-p1) + 8) >> 4 as two multiply-adds (v_pk_mad_i16) */
-    pk delta;
+    NormalK k;
+    k.c = splat_u(2 * tc); k.negc = splat_u(-2 * tc);
+    k.c2 = splat_u(tc >> 1); k.negc2 = splat_u(-(tc >> 1));
+    k.lim = splat_u(10 * tc);
+    return k;
+}
+
+/* (9(q0-p0) - 3(q1-p1) + 8) >> 4 (cpu.h:1253) as two multiply-adds (v_pk_mad_i16) */
+template <bool WIDE>
+DBK_HD pk normal_delta(const Taps &t)
+{
     if constexpr (WIDE) {
         /* 9a - 3b + 8 = 8a + r with r = a - 3b + 8 (|r| <= 16,388): (8a + r) >> 4 == (a + (r >> 3)) >> 1, floors included:
          * r = 8t + rho, 0 <= rho < 8, adds rho/16 < 1/2 to (a + t)/2, which cannot reach the next integer */
         const pk a = t.q0 - t.p0;
         const pk r = mad_k<-3>(t.q1 - t.p1, a + splat(8));
-        delta = (a + (r >> 3)) >> 1;
+        return (a + (r >> 3)) >> 1;
     } else {
-        delta = mad_k<9>(t.q0 - t.p0, mad_kc<-3, 8>(t.q1 - t.p1)) >> 4;
+        return mad_k<9>(t.q0 - t.p0, mad_kc<-3, 8>(t.q1 - t.p1)) >> 4;
     }
-    const pk on = (pk_abs(delta) - lim) >> 15;       /* all ones where |delta| < 10*tc (cpu.h:1254) */
-    const pk D = pk_clamp(delta, zero - c, c);
+}
+
+/* normal filter (cpu.h:1251-1354) of one line pair given its delta, up to, but not including, the final Clip2 to
+ * [0, max_v]; m5 / m6 = all-ones halves where cond5 / cond6 hold.  ALL_ON: the caller has established that
+ * |delta| < 10*tc (cpu.h:1254) holds in every line of every lane of the wave, so no per-line mask is needed */
+template <bool ALL_ON>
+DBK_HD void normal_apply(Taps &t, pk delta, const NormalK &k, pk m5, pk m6)
+{
+    const pk D = pk_min(pk_max(delta, k.negc), k.c);
     /* (((p2+p0+1)>>1) - p1 + D) >> 1  ==  (p2 + p0 + 1 - 2*p1 + 2*D) >> 2   (floor of a floor: the dropped
      * bit of the inner shift is worth 1/4 and cannot carry across an integer) */
     const pk xp = uaddc(uadd(t.p2, t.p0), 0x00010001u);
     const pk xq = uaddc(uadd(t.q2, t.q0), 0x00010001u);
-    const pk dp1 = pk_clamp(mad_k<2>(D, mad_k<-2>(t.p1, xp)) >> 2, zero - c2, c2);
-    const pk dq1 = pk_clamp(mad_k<-2>(D, mad_k<-2>(t.q1, xq)) >> 2, zero - c2, c2);
-    const pk Dm = D & on;
-    t.p0 = t.p0 + Dm;
-    t.q0 = t.q0 - Dm;
-    t.p1 = t.p1 + (dp1 & on & m5);
-    t.q1 = t.q1 + (dq1 & on & m6);
+    const pk dp1 = pk_min(pk_max(mad_k<2>(D, mad_k<-2>(t.p1, xp)) >> 2, k.negc2), k.c2);
+    const pk dq1 = pk_min(pk_max(mad_k<-2>(D, mad_k<-2>(t.q1, xq)) >> 2, k.negc2), k.c2);
+    if constexpr (ALL_ON) {
+        t.p0 = t.p0 + D;
+        t.q0 = t.q0 - D;
+        t.p1 = t.p1 + (dp1 & m5);
+        t.q1 = t.q1 + (dq1 & m6);
+    } else {
+        const pk on = (pk_abs(delta) - k.lim) >> 15; /* all ones where |delta| < 10*tc (cpu.h:1254) */
+        const pk Dm = D & on;
+        t.p0 = t.p0 + Dm;
+        t.q0 = t.q0 - Dm;
+        t.p1 = t.p1 + (dp1 & on & m5);
+        t.q1 = t.q1 + (dq1 & on & m6);
+    }
+}
+
+/* true in a lane where a line of the pair fails |delta| < 10*tc: with t = delta + (10*tc - 1) the test is
+ * 0 <= t <= 2*(10*tc) - 2 in both halves, compared as UNSIGNED 16-bit numbers (a negative t wraps to >= 32768).
+ * 10*tc <= 32767 and |delta| <= 3071 (packed_luma_tc_fits, 12 bit) keep t and the bound inside 16 bits. */
+DBK_HD bool normal_some_line_off(pk delta, const NormalK &k)
+{
+    const uint32_t lim = pk_bits(k.lim) & 0xffffu;
+    const uint32_t t = pk_bits(delta + bits_pk(pk_bits(k.lim) - 0x00010001u));
+    const uint32_t bound = 2u * lim - 2u; /* tc == 0 never asks */
+    return (t & 0xffffu) > bound || (t >> 16) > bound;
+}
+
+/* wave-level "does any active lane say yes": on the GPU one ballot; in the CPU build of this header (one block at a
+ * time) the lane's own answer */
+DBK_HD bool any_lane(bool v)
+{
+#if DBK_DEV
+    return __builtin_amdgcn_ballot_w64(v) != 0ull;
+#else
+    return v;
+#endif
 }
 
 /* both pairs of a normal-filtered segment.  The final Clip2 (cpu.h:1268-1275) only ever acts on samples
  * within 2*tc of 0 or max_v; one OR over the eight results shows whether any field left [0, max_v]
  * (a negative field has its top bits set, a too-large one has a bit above max_v), and the 16
- * min/max instructions run only in waves where some lane needs them. */
+ * min/max instructions run only in waves where some lane needs them.  Likewise the |delta| < 10*tc switch of a line
+ * (cpu.h:1254): a line fails it only across a real picture edge, so the per-line masks are built only in waves where
+ * some lane has such a line. */
 template <bool WIDE = false>
 DBK_HD void normal_pairs(Taps &a, Taps &b, int tc, pk m5, pk m6, int max_v)
 {
-    normal_pair_unclipped<WIDE>(a, tc, m5, m6);
-    normal_pair_unclipped<WIDE>(b, tc, m5, m6);
+    const NormalK k = normal_k(tc);
+    {
+        const pk da = normal_delta<WIDE>(a);
+        if (any_lane(tc > 0 ? normal_some_line_off(da, k) : true)) normal_apply<false>(a, da, k, m5, m6);
+        else normal_apply<true>(a, da, k, m5, m6);
+    }
+    {
+        const pk db = normal_delta<WIDE>(b);
+        if (any_lane(tc > 0 ? normal_some_line_off(db, k) : true)) normal_apply<false>(b, db, k, m5, m6);
+        else normal_apply<true>(b, db, k, m5, m6);
+    }
     const uint32_t over = (pk_bits(a.p0) | pk_bits(a.q0) | pk_bits(a.p1) | pk_bits(a.q1) |
                            pk_bits(b.p0) | pk_bits(b.q0) | pk_bits(b.p1) | pk_bits(b.q1)) &
                           (0x00010001u * (0xffffu & ~(uint32_t)max_v));
@@ -305,8 +368,7 @@ DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc, int max_v = 255, int 
         strong_pair<WIDE>(a, c);
         strong_pair<WIDE>(b, c);
     } else if (ablate != 2) {
-        const pk m5 = splat(d.cond5 ? -1 : 0), m6 = splat(d.cond6 ? -1 : 0);
-        normal_pairs<WIDE>(a, b, tc, m5, m6, max_v);
+        normal_pairs<WIDE>(a, b, tc, mask_of(d.cond5), mask_of(d.cond6), max_v);
     }
     return true;
 }

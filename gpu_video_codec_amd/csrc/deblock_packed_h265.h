@@ -99,7 +99,7 @@ DBK_HD void luma_pairs_h265(Taps &a, Taps &b, int entry, int beta, int tc, int m
         strong_pair_h265(b, cp, cq);
     } else {
         const pk mp0 = splat(kp ? 0 : -1), mq0 = splat(kq ? 0 : -1);
-        const pk mp1 = splat((d.cond5 && !kp) ? -1 : 0), mq1 = splat((d.cond6 && !kq) ? -1 : 0);
+        const pk mp1 = mask_of(d.cond5 && !kp), mq1 = mask_of(d.cond6 && !kq);
         normal_pair_h265<WIDE>(a, tc, mp0, mq0, mp1, mq1);
         normal_pair_h265<WIDE>(b, tc, mp0, mq0, mp1, mq1);
         const uint32_t over = (pk_bits(a.p0) | pk_bits(a.q0) | pk_bits(a.p1) | pk_bits(a.q1) |

@@ -30,7 +30,7 @@ def run_pmc(counter, variant, frames, outdir, steps=3, extra=()):
     d = os.path.join(outdir, "%s_%s" % (counter, variant))
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1",
-           "--variant", variant, "--frames", str(frames), "--no-cpu-baseline", "--no-e2e"] + list(extra)
+           "--variant", variant, "--frames", str(frames), "--no-cpu-baseline", "--no-e2e", "--no-extra"] + list(extra)
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     vals = []
