@@ -19,6 +19,7 @@ struct Growable {
 
 struct hevcdbk_context {
     int device = 0;
+    int n_cus = 0; /* compute units (hipDeviceAttributeMultiprocessorCount): sizes the persistent stripe launches */
     hipStream_t compute = nullptr, h2d = nullptr, d2h = nullptr;
     hipEvent_t ev[16] = {};
     std::string last_error;

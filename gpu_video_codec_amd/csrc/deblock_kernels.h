@@ -27,8 +27,23 @@ struct DbkArgs {
     uint32_t magic_wpf, magic_nbx;  /* floor(2^32/d)+1 reciprocals */
     int xcd_swizzle;                /* renumber workgroups so each XCD gets a contiguous range */
     int map_override;               /* block -> lane map of the packed kernels: 0 = chosen from the geometry, 1 = one
-                                       workgroup per block row, 2 = row-major numbering (HEVCDBK_MAP_* of the C ABI) */
+                                       workgroup per block row, 2 = row-major numbering (HEVCDBK_MAP_* of the C ABI); 3 = stripes,
+                                       diagnostic build only (HEVCDBK_DIAG_MAP_STRIPE) */
+    int n_cus;                      /* compute units of the device (0 = unknown: 256) */
 #ifdef HEVCDBK_DIAG /* the diagnostic build only (libhevcdbk_diag.so, hevcdbk_diag.h): never in the product library */
+    /* stripe map of the 8-bit luma kernel (dbk_stripe_kernel; filled by dbk_launch_packed): the blocks bx = 1..nbx-1 of
+     * the block rows 1..nby-2 are dealt to persistent one-wave workgroups that walk down the frames, the frame border
+     * (row 0, row nby-1, column 0) goes to extra workgroups of the same launch */
+    int st_M;                       /* blocks per row handled by the stripes: nbx - 1 (even) */
+    int st_k;                       /* block rows per row group */
+    int st_W;                       /* wave slots per row group: ceil(k*M / 64) */
+    int st_Q;                       /* persistent workgroups (one per stripe) */
+    int st_groups;                  /* row groups per frame: ceil((nby - 2) / k) */
+    int st_items;                   /* n_frames * groups: one item = one row group of one frame */
+    int st_border_wgs;              /* workgroups (W waves each) at the START of the grid that run the frame border */
+    int st_lds_bytes;               /* dynamic LDS of a workgroup: W * (4096 + 256) */
+    int st_border_wpf;              /* border waves per frame: ceil((2*nbx + nby - 2) / 64) */
+    uint32_t st_magic_M, st_magic_groups, st_magic_bwpf; /* floor(2^32/d)+1 reciprocals */
     int use_queue;   /* 8-bit luma: strong segments scheduled through the workgroup's LDS queue */
     int diag_ablate; /* 1 = strong segments filtered as normal, 2 = normal filter skipped, 4 = barriers (WRONG pixels) */
     int diag_xshift; /* copy mode only: byte shift of every row span (alignment experiments) */

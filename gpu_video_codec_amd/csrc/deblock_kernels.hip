@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -33,12 +34,13 @@ void dbk_set_next_launch_events(hipEvent_t start, hipEvent_t stop)
     t_next_start = start;
     t_next_stop = stop;
 }
-#define DBK_LAUNCH(kernel, grid, block, stream, ...)                                              \
+#define DBK_LAUNCH_LDS(kernel, grid, block, lds_bytes, stream, ...)                               \
     do {                                                                                           \
         hipEvent_t s_ = t_next_start, e_ = t_next_stop;                                            \
         t_next_start = t_next_stop = nullptr;                                                      \
-        hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, s_, e_, 0, __VA_ARGS__);             \
+        hipExtLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, s_, e_, 0, __VA_ARGS__);     \
     } while (0)
+#define DBK_LAUNCH(kernel, grid, block, stream, ...) DBK_LAUNCH_LDS(kernel, grid, block, 0, stream, __VA_ARGS__)
 
 namespace {
 
@@ -656,6 +658,228 @@ __global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiAr
     }
 }
 
+#ifdef HEVCDBK_DIAG
+/* ------------------------------------------------------------------------------------------ */
+/* 8-bit luma, scalar QP: the STRIPE map -- persistent waves, the next tile prefetched into LDS  */
+/* DIAGNOSTIC BUILD ONLY (measured slower than the plain maps on MI355X; bit-exact, kept for A/B runs).
+ *
+ * Why: with one launch-and-forget wave per 64 blocks (the maps above) a SIMD holds 8 tiles; each is either waiting for its
+ * rows, or being filtered, or waiting for its stores.  The filter keeps the VALU ~95 % busy and the row loads and stores
+ * keep the memory system ~90 % busy, and with only 8 customers circulating between two nearly saturated servers neither
+ * reaches 100 % (measured: removing 7 % of the VALU work bought 1 %).  Here a wave is persistent and owns a STRIPE of the
+ * batch: it walks through "items" (one item = one group of k block rows of one frame), and while it filters the tile of
+ * item n its tile of item n + Q is already on its way from HBM into the wave's 4 KiB of LDS (buffer_load_dwordx4 ... lds:
+ * no VGPRs, no VALU, 16 bytes per lane).  Two tiles per wave are in flight without a single extra register.
+ *
+ * Tile = 64 consecutive blocks of the row group's row-major numbering t = rowg*M + (bx - 1), M = nbx - 1: the stripes cover
+ * bx = 1..nbx-1 of the block rows 1..nby-2 (all 8 pixel rows inside the image, left halves inside the image), so with
+ * k*M a multiple of 64 (4K: k = 2 rows, 15 wave slots) no lane idles.  What is left -- block row 0, block row nby-1 and
+ * the column bx = 0 -- is the frame border: extra one-wave workgroups at the end of the same grid run it through the
+ * per-lane path (PATH 2) of the plain kernel.
+ *
+ * LDS image of a tile: 8 pixel rows x 512 bytes, lane j's row r at 512*r + 8*j.  One LDS-DMA instruction moves 1 KiB =
+ * two pixel rows: lanes 0..31 row 2q, lanes 32..63 row 2q+1, 16 bytes = the blocks 2m, 2m+1 of the tile (M is even, so a
+ * pair never straddles a row end).  The workgroup -> (slot, stripe) map keeps the W waves of a row group on one XCD
+ * (workgroups are dealt round-robin over the 8 XCDs, an observation used for speed only): neighbouring tiles share the
+ * 128-byte line at their common boundary, and the shared reads and the two partial writes then meet in one L2.
+ */
+__device__ __forceinline__ uint32_t div_magic(uint32_t x, uint32_t d, uint32_t magic)
+{
+    return d == 1u ? x : __umulhi(x, magic); /* magic = floor(2^32/d) + 1, exact for x < 2^32 / d */
+}
+
+constexpr int kStripeLdsPerWave = 4096 + 256; /* 8 pixel rows x 512 bytes, then 4 x 64 bS bytes */
+
+template <int MODE> /* 0 = filter; 1 = copy (diagnostic build only) */
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void dbk_stripe_kernel(const DbkArgs a)
+{
+    /* one workgroup = the W wave slots of a row group: neighbouring tiles share the 128-byte line at their common boundary,
+     * and with their waves on one CU, working on the same item, the shared reads coalesce and the two partial writes of
+     * such a line meet in the L2 within microseconds (measured: with the slots spread over workgroups that drift apart
+     * the same copy ran 14 % slower) */
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile_all[]; /* W * kStripeLdsPerWave bytes */
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* wave slot inside the row group */
+    uint8_t *const tile = tile_all + w * (uint32_t)kStripeLdsPerWave;
+    lds_u8 *const tile_lds = (lds_u8 *)tile; /* the LDS-DMA destination (M0) */
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t W = (uint32_t)a.st_W, M = (uint32_t)a.st_M, k = (uint32_t)a.st_k, Q = (uint32_t)a.st_Q;
+
+    if (blockIdx.x < (uint32_t)a.st_border_wgs) {
+        /* the frame border, one lane per block; these workgroups come FIRST in the grid so that they run beside the
+         * stripes instead of after them */
+        const uint32_t idx = blockIdx.x * W + w;
+        const uint32_t f = div_magic(idx, (uint32_t)a.st_border_wpf, a.st_magic_bwpf);
+        if (f >= (uint32_t)a.n_frames) return; /* padding wave of the last border workgroup */
+#ifdef HEVCDBK_DIAG
+        if (MODE == 1 && (a.diag_dummy & 8)) return; /* timing experiment: no border */
+#endif
+        const uint32_t u = (idx - f * (uint32_t)a.st_border_wpf) * 64u + lane;
+        const uint32_t nbx = (uint32_t)a.nbx, nby = (uint32_t)a.nby;
+        int by = 0, bx = 0;
+        bool active = true;
+        if (u < nbx) { by = 0; bx = (int)u; }
+        else if (u < 2u * nbx) { by = (int)nby - 1; bx = (int)(u - nbx); }
+        else if (u < 2u * nbx + nby - 2u) { by = 1 + (int)(u - 2u * nbx); bx = 0; }
+        else active = false;
+        packed_body<false, MODE, false, 2, false>(a, by, (int)f, bx, active, 0);
+        return;
+    }
+
+    const uint32_t q = blockIdx.x - (uint32_t)a.st_border_wgs; /* stripe number: items q, q + Q, q + 2Q, ... */
+    const uint32_t n_items = (uint32_t)a.st_items, groups = (uint32_t)a.st_groups;
+    uint32_t item = q;
+    if (item >= n_items) return;
+
+    const uint32_t pitch = (uint32_t)a.pitch;
+    /* this lane's block inside the row group, and the pair of blocks this lane moves by LDS-DMA */
+    const uint32_t t = w * 64u + lane;
+    const uint32_t rowg = __umulhi(t, a.st_magic_M);
+    const uint32_t bx = 1u + t - rowg * M;
+    const uint32_t tp = w * 64u + 2u * (lane & 31u);
+    const uint32_t rowp = __umulhi(tp, a.st_magic_M);
+    const uint32_t bxp = 1u + tp - rowp * M;
+#ifdef HEVCDBK_DIAG /* copy variant, knob "align": every span 4 bytes to the left, i.e. naturally aligned (timing only) */
+    const uint32_t dshift = MODE == 1 ? (uint32_t)a.diag_xshift : 0u;
+#else
+    const uint32_t dshift = 0u;
+#endif
+    const uint32_t voff_dma = (rowp * 8u + (lane >> 5)) * pitch + bxp * 8u - 4u - dshift;
+    const uint32_t voff_dma_idle = (lane >> 5) * pitch + 4u;   /* any valid address: lanes past the group's last row */
+    const uint32_t voff_st = rowg * 8u * pitch + bx * 8u - 4u - dshift;
+    const bool redge = bx == (uint32_t)a.nbx - 1u;             /* right half outside the image */
+    const bool wave_has_redge = __builtin_amdgcn_ballot_w64(redge && rowg < k) != 0ull;
+    const bool hor2_ok = bx < (uint32_t)a.limit_bx;            /* cpu.h:369: only the right-edge block fails */
+
+    /* ONE buffer resource per array for the whole batch (the launcher takes this map only while a batch stays below
+     * 4 GiB): the frame goes into the 32-bit scalar offset, so an item costs a handful of scalar multiplies and no
+     * 64-bit address arithmetic, and the resources never change */
+    const uint32_t fstride = (uint32_t)a.frame_stride;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.src), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.vert_bs), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.hor_bs), 0, 0xffffffffu, 0x00020000);
+
+#define DBK_STRIPE_COORDS(it, f_, by0_, rows_)                                                      \
+    const uint32_t f_ = div_magic((it), groups, a.st_magic_groups);                                 \
+    const uint32_t by0_ = 1u + ((it) - f_ * groups) * k;                                            \
+    const uint32_t rows_ = ((uint32_t)a.nby - 1u - by0_) < k ? ((uint32_t)a.nby - 1u - by0_) : k;
+
+    auto issue_dma = [&](uint32_t it) {
+        DBK_STRIPE_COORDS(it, f, by0, rows)
+        const uint32_t v = rowp < rows ? voff_dma : voff_dma_idle;
+        const uint32_t s0 = f * fstride + (by0 * 8u - 4u) * pitch;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, tile_lds + 0, 16, v, s0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, tile_lds + 1024, 16, v, s0 + 2u * pitch, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, tile_lds + 2048, 16, v, s0 + 4u * pitch, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, tile_lds + 3072, 16, v, s0 + 6u * pitch, 0, 0);
+    };
+    /* the bS bytes of the tile's 64 blocks are 64 consecutive bytes of each array per row of the group (two runs in a
+     * tile that straddles rows; M % 16 == 0 keeps a run boundary off the middle of a 16-byte piece): they travel by
+     * LDS-DMA too -- lanes 0..3 ver1 (cpu.h:161), 4..7 ver2 (cpu.h:225) / lanes 0..3 hor1 (cpu.h:289), 4..7 hor2
+     * (cpu.h:370), 16 bytes each -- so that the loop holds no register-returning vector load at all: the compiler does not
+     * count LDS-DMA when it places waits for such loads, and its waits would drain the prefetch. */
+    const uint32_t tb = w * 64u + 16u * (lane & 3u);                 /* first block of this lane's 16-byte piece */
+    const uint32_t rowb = __umulhi(tb, a.st_magic_M), bxb = 1u + tb - rowb * M;
+    /* the buffer range check sees the vector offset alone, so it must not go negative: "the row above" of ver1 sits in
+     * the scalar offset ((by0 - 1) * vstride, by0 >= 1) and ver2 adds a row here */
+    const uint32_t bsv_p = (rowb + ((lane & 4u) ? 1u : 0u)) * (uint32_t)a.vstride + bxb;
+    const uint32_t bsh_p = rowb * (uint32_t)a.hstride + bxb - ((lane & 4u) ? 0u : 1u);                  /* hor1: bx - 1 >= 0 */
+    auto issue_bs_dma = [&](uint32_t it) {
+        DBK_STRIPE_COORDS(it, f, by0, rows)
+        (void)rows;
+        if (lane < 8u) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, tile_lds + 4096, 16, bsv_p,
+                                                     f * (uint32_t)a.vert_bs_stride + (by0 - 1u) * (uint32_t)a.vstride, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, tile_lds + 4224, 16, bsh_p,
+                                                     f * (uint32_t)a.hor_bs_stride + by0 * (uint32_t)a.hstride, 0, 0);
+        }
+    };
+#ifdef HEVCDBK_DIAG /* timing experiments on the copy variant: bit 0 no bS DMA, bit 1 no stores, bit 2 no tile DMA */
+    const int sx = MODE == 1 ? a.diag_dummy : 0;
+#else
+    constexpr int sx = 0;
+#endif
+    auto issue_all = [&](uint32_t it) {
+        if (!(sx & 4)) issue_dma(it);
+        if (!(sx & 1)) issue_bs_dma(it);
+    };
+
+    /* Order of the vector-memory operations of a wave, which is what its vmcnt counts (in issue order):
+     *   tile(n+1) LDS-DMA x4, bS(n+1) LDS-DMA x2  -- issued at the top of item n, before its arithmetic
+     *   stores(n) x8 (x16 in a wave that holds a right-edge block)
+     * so "everything but the stores has arrived" is vmcnt(8 / 16). */
+    issue_all(item);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (;;) {
+        uint32_t L[8], R[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const u32x2 wv = *reinterpret_cast<const u32x2 *>(tile + 512 * r + 8 * lane);
+            L[r] = wv.x;
+            R[r] = wv.y;
+        }
+        DBK_STRIPE_COORDS(item, f, by0, rows)
+        const bool act = rowg < rows;
+        dbk::BlockBs bs; /* by >= 1, by <= nby-2, bx >= 1: the only guard that can fail is hor2's (cpu.h:369) */
+        bs.ver1 = act ? (int)tile[4096 + lane] : 0;
+        bs.ver2 = act ? (int)tile[4160 + lane] : 0;
+        bs.hor1 = act ? (int)tile[4224 + lane] : 0;
+        bs.hor2 = (act && hor2_ok) ? (int)tile[4288 + lane] : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* tile and bS are in registers: the LDS may be refilled */
+        const uint32_t next = item + Q;
+        const bool has_next = next < n_items;
+        if (has_next) issue_all(next);
+
+        if (wave_has_redge) {
+            if (redge) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) R[r] = 0u; /* the bytes fetched there belong to the next pixel row */
+            }
+        }
+        if constexpr (MODE == 0) {
+            const dbk::BlockQp qp = block_qp<false, false>(a, (int)f, 0, 0);
+            dbk::packed_filter_block<false>(L, R, bs, qp);
+        }
+
+        const uint32_t s0 = f * fstride + (by0 * 8u - 4u) * pitch;
+#ifdef HEVCDBK_DIAG
+        if (a.diag_dummy & 16) __builtin_amdgcn_s_barrier(); /* experiment: the row group's waves store together */
+#endif
+        if (sx & 2) {
+            if (L[0] == 0x12345678u && R[7] == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b32(L[3] ^ R[5], rd, kOob, 0, 0);
+        } else if (wave_has_redge) {
+            const uint32_t vfull = (act && !redge) ? voff_st : kOob, vhalf = (act && redge) ? voff_st : kOob;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                u32x2 wv;
+                wv.x = L[r];
+                wv.y = R[r];
+                __builtin_amdgcn_raw_buffer_store_b64(wv, rd, vfull, s0 + (uint32_t)r * pitch, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, vhalf, s0 + (uint32_t)r * pitch, 0);
+            }
+        } else {
+            const uint32_t vfull = act ? voff_st : kOob;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                u32x2 wv;
+                wv.x = L[r];
+                wv.y = R[r];
+                __builtin_amdgcn_raw_buffer_store_b64(wv, rd, vfull, s0 + (uint32_t)r * pitch, 0);
+            }
+        }
+        if (!has_next) break;
+        item = next;
+        /* the next tile and its bS bytes were requested BEFORE this item's stores: wait for everything but the stores */
+        if (sx & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (wave_has_redge) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+#undef DBK_STRIPE_COORDS
+}
+
+#endif /* HEVCDBK_DIAG: stripe map */
+
 #ifdef HEVCDBK_DIAG /* measured and rejected; kept in the diagnostic build for A/B runs */
 /* ------------------------------------------------------------------------------------------ */
 /* 8-bit luma with workgroup-level scheduling of the strong filter                              */
@@ -1024,6 +1248,75 @@ static bool plan_packed(const DbkArgs &a, DbkArgs &b, dim3 &grid, dim3 &block)
     return false;
 }
 
+#ifdef HEVCDBK_DIAG
+/* the stripe map (dbk_stripe_kernel): 8-bit luma, scalar QP, whole planes, an even number of blocks per row beside the
+ * left border column; fills the st_* fields of `b` and the launch size */
+static bool plan_stripe(const DbkArgs &a, DbkArgs &b, int sample_bytes, bool chroma, unsigned &grid)
+{
+    if (sample_bytes != 1 || chroma || a.qp_map || a.by_count != 0 || a.max_v != 255) return false;
+    const long long M = a.nbx - 1, rows = a.nby - 2;
+    if (M < 16 || (M % 16) || rows < 1) return false; /* pairs / 16-byte bS pieces never straddle a row end */
+    /* row group: k rows whose k*M blocks fill whole waves as nearly as possible (4K: M = 480, k = 2 -> 15 waves, none idle) */
+    int k = 1;
+    double best = 2.0;
+    for (int c = 1; c <= 8 && c <= rows; c++) {
+        const long long waves = (c * M + 63) / 64;
+        const double waste = (double)(waves * 64 - c * M) / (double)(waves * 64);
+        if (waste + 1e-9 < best) { best = waste; k = c; }
+    }
+    const long long W = (k * M + 63) / 64, groups = (rows + k - 1) / k, items = groups * a.n_frames;
+    /* exact reciprocal division: dividend < 2^32 / divisor */
+    if (items * groups >= (1ll << 32) || (W * 64) * M >= (1ll << 32)) return false;
+    if (W > 16) return false;
+    /* one buffer resource per array for the whole batch, frames addressed through the 32-bit scalar offset */
+    if ((unsigned long long)a.frame_stride * (unsigned long long)a.n_frames >= (1ull << 32) ||
+        (unsigned long long)a.vert_bs_stride * (unsigned long long)a.n_frames + (unsigned long long)a.n_vert >= (1ull << 32) ||
+        (unsigned long long)a.hor_bs_stride * (unsigned long long)a.n_frames + (unsigned long long)a.n_hor >= (1ull << 32))
+        return false;
+    /* persistent workgroups: as many as are resident at once (W waves, W * kStripeLdsPerWave bytes of LDS each) */
+    const size_t lds = (size_t)W * kStripeLdsPerWave;
+    static int wgs_per_cu_cache[17] = {0};
+    if (wgs_per_cu_cache[W] == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dbk_stripe_kernel<0>, (int)(64 * W), lds) != hipSuccess || n <= 0)
+            n = (int)(28 / W) > 0 ? (int)(28 / W) : 1;
+        wgs_per_cu_cache[W] = n;
+    }
+    const int wgs_per_cu = wgs_per_cu_cache[W];
+    long long Q = (long long)(a.n_cus > 0 ? a.n_cus : 256) * wgs_per_cu;
+    if (Q > items) Q = items;
+    const long long bwpf = (2ll * a.nbx + a.nby - 2 + 63) / 64;
+    const long long border_wgs = (bwpf * a.n_frames + W - 1) / W, total = border_wgs + Q;
+    if (total >= (1ll << 31) || (border_wgs * W + 16) * bwpf >= (1ll << 32)) return false;
+    auto magic = [](long long d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (unsigned long long)d + 1ull); };
+    b.st_M = (int)M;
+    b.st_k = k;
+    b.st_W = (int)W;
+    b.st_Q = (int)Q;
+    b.st_groups = (int)groups;
+    b.st_items = (int)items;
+    b.st_border_wgs = (int)border_wgs;
+    b.st_lds_bytes = (int)lds;
+    b.st_border_wpf = (int)bwpf;
+    b.st_magic_M = magic(M);
+    b.st_magic_groups = magic(groups);
+    b.st_magic_bwpf = magic(bwpf);
+    grid = (unsigned)total;
+#ifdef HEVCDBK_DIAG
+    {
+        static bool said = false;
+        if (!said) {
+            said = true;
+            fprintf(stderr, "[diag] stripe plan: M %lld k %d W %lld Q %lld groups %lld items %lld WGs/CU %d CUs %d border waves/frame %lld border WGs %lld grid %u\n",
+                    M, k, W, Q, groups, items, wgs_per_cu, a.n_cus, bwpf, border_wgs, grid);
+        }
+    }
+#endif
+    return true;
+}
+
+#endif /* HEVCDBK_DIAG */
+
 hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, int mode, hipStream_t stream)
 {
     if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
@@ -1034,7 +1327,20 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
     b.diag_dummy = g_dbk_diag.dummy;
     b.use_queue = g_dbk_diag.queue;
     b.diag_xshift = (mode == 1 && g_dbk_diag.align) ? 4 * sample_bytes : 0;
-#else
+#endif
+#ifdef HEVCDBK_DIAG
+    if (a.map_override == 3) { /* HEVCDBK_DIAG_MAP_STRIPE */
+        unsigned sgrid = 0;
+        const DbkArgs b0 = b;
+        if (plan_stripe(b0, b, sample_bytes, chroma, sgrid)) {
+            if (mode == 1) DBK_LAUNCH_LDS((dbk_stripe_kernel<1>), dim3(sgrid), dim3(64 * b.st_W), b.st_lds_bytes, stream, b);
+            else DBK_LAUNCH_LDS((dbk_stripe_kernel<0>), dim3(sgrid), dim3(64 * b.st_W), b.st_lds_bytes, stream, b);
+            return hipGetLastError();
+        }
+        b = b0; /* operands the stripes do not take: the geometry's own map */
+    }
+#endif
+#ifndef HEVCDBK_DIAG
     if (mode != 0) return hipErrorInvalidValue; /* the copy diagnostic exists in libhevcdbk_diag.so only */
 #endif
     dim3 grid, block;

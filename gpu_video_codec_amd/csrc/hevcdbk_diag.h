@@ -16,6 +16,12 @@ extern "C" {
  * kernel's loads and stores with no arithmetic (dst = src) -- the memory-path ceiling of the access pattern */
 #define HEVCDBK_DIAG_KERNEL_COPY 100
 
+/* block map selector (OR-ed into the kernel selector like HEVCDBK_MAP_*), diagnostic library only: persistent waves
+ * walking down stripes of the batch, the next tile and its bS bytes prefetched into LDS by buffer_load ... lds
+ * (8-bit luma, scalar QP, width a multiple of 128; other operands take the geometry's own map).  Bit-exact; measured
+ * SLOWER than the plain maps on MI355X, which is why it is not in the product. */
+#define HEVCDBK_DIAG_MAP_STRIPE 0x300
+
 /* comma-separated knobs, process-wide, replacing the previous set (NULL or "" = defaults):
  *   wg=N      workgroup width cap of the packed kernels (64..1024, default 512)
  *   noswz     row-major map without the per-XCD workgroup renumbering
@@ -25,7 +31,9 @@ extern "C" {
  *   align     copy variant: row spans shifted onto their natural alignment
  *   mode3     8-bit luma through the instrumented instantiation of the kernel with no knob active (A/B baseline)
  *   prio=N    wave priority experiment: bit 0 = s_setprio 3 until the row loads are issued, bit 1 = from the final pack on
- *   dummy=N   N extra VALU instructions per wave (how the kernel time responds to VALU work)
+ *   dummy=N   N extra VALU instructions per wave (how the kernel time responds to VALU work); with the stripe map
+ *             a bit set of timing experiments instead: 1 no bS DMA, 2 no stores, 4 no tile DMA, 8 no border,
+ *             16 a workgroup barrier before the stores
  *   nostrong | nonormal | barriers   luma ablations -- WRONG PIXELS, timing only
  * returns HEVCDBK_OK or HEVCDBK_ERR_ARG (unknown knob; nothing changed) */
 HEVCDBK_API int hevcdbk_diag_set(const char *spec);

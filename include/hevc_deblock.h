@@ -184,7 +184,7 @@ typedef struct {
 #define HEVCDBK_MAP_AUTO   0x000
 #define HEVCDBK_MAP_ROWS   0x100 /* one workgroup per block row */
 #define HEVCDBK_MAP_LINEAR 0x200 /* row-major block numbering, workgroups renumbered per XCD */
-#define HEVCDBK_MAP_MASK   0x300
+#define HEVCDBK_MAP_MASK   0x700
 
 HEVCDBK_API int hevc_deblocking_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes,
                                   unsigned qp, const hevcdbk_tables *tables, int kernel_variant,

@@ -197,3 +197,46 @@ def test_only_the_api_leaves_the_library():
     internal = [n for n in names if n.startswith("dbk_") or n in ("filter_chunk", "h265_args", "launch_h265") or "dbk_launch" in n]
     assert not internal, internal
     assert set(_lib.EXPORTS) <= set(names)
+
+
+REF_MAIN = "/root/reference/hevc_deblocking_filter/main.cu"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="the reference lives in the build container only")
+def test_reference_driver_links_against_the_library(tmp_path):
+    """INTEGRATION.md section 1, executed: tools/port_main_cu.py applies the listed edits to a copy of the reference's
+    main.cu made here at test time (drop the four CUDA includes main.cu:20-21,27-28, the addWithCuda declaration
+    main.cu:85, swap the body of GetGpuDeviceInfo main.cu:92-107); the result is plain C++ that compiles against the
+    reference's own CPU header and links against libhevcdbk.so -- ExecuteGpu (main.cu:87-90) resolves to the library's
+    C++ symbol.  Run in a directory holding the bundled input: ExecuteCpu (the reference's code) writes the reference
+    output; without a GPU the following ExecuteGpu call fails loudly (no CPU fallback).  On the GPU box, where the
+    reference is absent, the committed hevc_deblock_main driver covers the same call (tests/test_gpu_parity.py)."""
+    import shutil
+    import subprocess
+    import sys
+    from gpu_video_codec_amd import _lib
+    from conftest import GOLDEN, sha256
+    ported = tmp_path / "main_ported.cpp"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "port_main_cu.py"), REF_MAIN, str(ported)])
+    text = ported.read_text(errors="replace")
+    assert "cuda" not in text.lower().replace("addwithcuda", "") and "hevcdbk_get_device_info" in text
+    exe = tmp_path / "deblock"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["g++", "-x", "c++", "-std=c++14", "-O2", "-fopenmp", "-I", os.path.join(ROOT, "include"),
+                        "-I", os.path.dirname(REF_MAIN), str(ported), "-L", libdir, "-lhevcdbk",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    und = subprocess.check_output(["nm", "-C", "--undefined-only", str(exe)]).decode()
+    assert "ExecuteGpu(std::" in und and "hevcdbk_create" in und   # resolved by libhevcdbk.so at load time
+    shutil.copy(os.path.join(GOLDEN, "mother-daughter_352x288_yv12.yuv"), tmp_path)
+    run = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    cpu_out = tmp_path / "mother-daughter_352x288_yv12_filtered.yuv"      # main.cu:129
+    assert cpu_out.exists(), run.stdout[-2000:] + run.stderr[-2000:]
+    with open(os.path.join(GOLDEN, "mother-daughter_qp35.ref.yuv"), "rb") as fh:
+        assert sha256(cpu_out.read_bytes()) == sha256(fh.read())
+    gpu_out = tmp_path / "mother-daughter_352x288_yv12_filtered_gpu.yuv"  # main.cu:130
+    from gpu_video_codec_amd import deblock
+    if deblock.device_count() > 0:
+        assert run.returncode == 0 and sha256(gpu_out.read_bytes()) == sha256(cpu_out.read_bytes())
+    else:
+        assert run.returncode != 0 and not gpu_out.exists()   # fails loudly: there is no CPU path in the library

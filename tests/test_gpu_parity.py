@@ -414,6 +414,30 @@ with deblock.Context(0) as ctx:
     y = frames["synth"]
     got = run_batch(ctx, np.stack([y]), 32, variant=_lib.DIAG_KERNEL_COPY)
     assert np.array_equal(got[0], y)
+    # the stripe map (HEVCDBK_DIAG_MAP_STRIPE): persistent waves, next tile and its bS bytes prefetched into LDS by
+    # buffer_load ... lds, frame border by extra workgroups of the same launch.  One and several waves per row group, rows
+    # per group 1..8, a last group that is not full, fewer items than persistent workgroups and many more, in place,
+    # per-frame random bS (every guard), a QP with tc = 0; operands it does not take fall back to the geometry's own map
+    rng = np.random.default_rng(4242)
+    variant = _lib.KERNEL_PACKED | _lib.DIAG_MAP_STRIPE
+    for (w, h, n) in [(3840, 72, 2), (3840, 136, 3), (1920, 264, 2), (1280, 72, 5), (512, 40, 3), (128, 24, 2), (256, 136, 40),
+                      (4096, 48, 1), (7680, 40, 1), (1024, 1032, 3)]:
+        fr = np.stack([synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30))) for _ in range(min(n, 4))])
+        fr = np.concatenate([fr] * (n // len(fr) + 1))[:n].copy()
+        fr[0, : h // 2, : w // 3] = rng.integers(0, 256, (h // 2, w // 3), dtype=np.uint8)
+        if n > 1:
+            fr[1] = fr[1][::-1]
+        bss = [oracle.lcg_bs(w, h, 5 + f) if f % 2 == 0 else oracle.default_bs(w, h) for f in range(n)]
+        for qp, in_place in ((37, False), (32, True), (17, False)):
+            got = run_batch(ctx, fr, qp, variant=variant, bs=bss, in_place=in_place)
+            for f in sorted({0, 1 % n, n // 2, n - 1}):
+                assert np.array_equal(got[f], oracle.filter_plane(fr[f], qp, vert_bs=bss[f][0], hor_bs=bss[f][1])), (w, h, n, qp, f)
+    y = synth.blocky_plane(520, 72, seed=3)
+    assert np.array_equal(run_batch(ctx, y[None], 37, variant=variant)[0], oracle.filter_plane(y, 37))
+    c = synth.blocky_plane(1920, 136, seed=4)
+    assert np.array_equal(run_batch(ctx, c[None], 40, variant=variant, is_chroma=True)[0], oracle.filter_plane(c, 40, is_chroma=True))
+    t = synth.blocky_plane(1920, 72, seed=5, bit_depth=10)
+    assert np.array_equal(run_batch(ctx, t[None], 32, variant=variant, bit_depth=10)[0], oracle.filter_plane(t, 32, bit_depth=10))
 print("DIAG-OK")
 """
 
@@ -432,6 +456,11 @@ def test_diagnostic_library_variants_are_bit_exact():
     instantiation with its knobs at rest, other workgroup widths and the wave-priority experiment."""
     _run_diag_child("queue")
     _run_diag_child("mode3,wg=256,prio=3")
+
+
+def test_stripe_map_barrier_variant():
+    """The stripe map once more with its "workgroup barrier before the stores" experiment switched on (knob dummy=16)."""
+    _run_diag_child("dummy=16")
 
 
 def test_product_library_has_no_diagnostics(ctx):

@@ -37,7 +37,7 @@ def main():
         vals = {}
         for fn in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(fn)):
-                if "dbk_packed" in row["Kernel_Name"]:
+                if "dbk_packed" in row["Kernel_Name"] or "dbk_stripe" in row["Kernel_Name"]:
                     vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
         for k, v in vals.items():
             v.sort()
