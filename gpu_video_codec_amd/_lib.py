@@ -24,7 +24,8 @@ EXPORTS = [
     "hevcdbk_strerror", "hevcdbk_device_count", "hevcdbk_create", "hevcdbk_destroy", "hevcdbk_last_error",
     "hevcdbk_get_device_info", "hevcdbk_default_tc_table", "hevcdbk_default_beta_table",
     "hevcdbk_num_vert_bs", "hevcdbk_num_hor_bs", "hevcdbk_default_bs",
-    "hevc_deblocking_filter", "hevc_deblocking_filter_device", "hevc_deblocking_filter_sequence",
+    "hevc_deblocking_filter", "hevc_deblocking_filter_device", "hevc_deblocking_filter_device_planes",
+    "hevc_deblocking_filter_sequence",
     "hevcdbk_device_malloc", "hevcdbk_device_free", "hevcdbk_host_malloc_pinned", "hevcdbk_host_free_pinned",
     "hevcdbk_memcpy_h2d", "hevcdbk_memcpy_d2h", "hevcdbk_memcpy_d2d", "hevcdbk_memset_d",
     "hevcdbk_synchronize", "hevcdbk_compute_stream", "hevcdbk_device_run_timed", "hevcdbk_execute_gpu",
@@ -138,6 +139,8 @@ def lib():
                                                       C.POINTER(Tables), C.POINTER(Timing)]
         L.hevc_deblocking_filter_device.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint,
                                                     C.POINTER(Tables), C.c_int, C.c_void_p]
+        L.hevc_deblocking_filter_device_planes.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint, C.c_uint,
+                                                           C.POINTER(Tables), C.c_int, C.c_void_p]
         L.hevcdbk_device_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.hevcdbk_device_free.argtypes = [C.c_void_p, C.c_void_p]
         L.hevcdbk_host_malloc_pinned.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]

@@ -527,6 +527,40 @@ int hevc_deblocking_filter_device(hevcdbk_context *ctx, const hevcdbk_device_pla
     return launch(ctx, a, (int)planes->sample_bytes, planes->is_chroma != 0, kernel_variant, s);
 }
 
+/* the planes of a batch: one fused launch where the fused kernel applies, else plane by plane */
+static int launch_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, const DbkArgs *args, unsigned n_planes,
+                         int kernel_variant, hipStream_t s)
+{
+    const int fam = kernel_variant & ~HEVCDBK_MAP_MASK, map = kernel_variant & HEVCDBK_MAP_MASK;
+    if (n_planes >= 2 && n_planes <= 3 && map == HEVCDBK_MAP_AUTO && (fam == HEVCDBK_KERNEL_AUTO || fam == HEVCDBK_KERNEL_PACKED) &&
+        !planes[0].is_chroma) {
+        int sbs[3] = {0, 0, 0};
+        bool ok = true;
+        for (unsigned i = 0; i < n_planes; i++) {
+            sbs[i] = (int)planes[i].sample_bytes;
+            ok = ok && (i == 0 || planes[i].is_chroma) && dbk_packed_supports(args[i], sbs[i], planes[i].is_chroma != 0);
+        }
+        if (ok && dbk_multi_supports(args, (int)n_planes, sbs))
+            return hip_ok(ctx, dbk_launch_packed_multi(args, (int)n_planes, s), "kernel launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    }
+    for (unsigned i = 0; i < n_planes; i++)
+        if (int rc = launch(ctx, args[i], (int)planes[i].sample_bytes, planes[i].is_chroma != 0, kernel_variant, s)) return rc;
+    return HEVCDBK_OK;
+}
+
+int hevc_deblocking_filter_device_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
+                                         unsigned qp, const hevcdbk_tables *tables, int kernel_variant, void *hip_stream)
+{
+    if (!ctx || !planes || n_planes == 0 || n_planes > 3) return HEVCDBK_ERR_ARG;
+    DbkArgs args[3];
+    for (unsigned i = 0; i < n_planes; i++) {
+        if (int rc = planes_to_args(&planes[i], qp, tables, args[i])) return rc;
+        if (planes[i].n_frames != planes[0].n_frames) return HEVCDBK_ERR_ARG;
+    }
+    if (int rc = bind(ctx)) return rc;
+    return launch_planes(ctx, planes, args, n_planes, kernel_variant, hip_stream ? (hipStream_t)hip_stream : ctx->compute);
+}
+
 int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
                              unsigned qp, const hevcdbk_tables *tables, int kernel_variant, unsigned steps,
                              float *kernel_ms)
@@ -544,7 +578,28 @@ int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *
     }
     /* the step's first launch stamps its own begin and the last one its own end into the events: kernel time as a
      * profiler's kernel trace sees it, and no barrier packets between the launches */
+    /* a step = hevc_deblocking_filter_device_planes over the planes handed in (one fused launch where that applies) */
+    bool same_frames = n_planes <= 3;
+    for (unsigned i = 1; i < n_planes; i++) same_frames = same_frames && planes[i].n_frames == planes[0].n_frames;
     for (unsigned s = 0; s < steps; s++) {
+        if (same_frames) {
+            /* probe once whether the step is ONE launch: then that launch stamps both events */
+            int sbs[3] = {0, 0, 0};
+            bool fused = n_planes >= 2 && !planes[0].is_chroma && (kernel_variant & HEVCDBK_MAP_MASK) == HEVCDBK_MAP_AUTO &&
+                         ((kernel_variant & ~HEVCDBK_MAP_MASK) == HEVCDBK_KERNEL_AUTO || (kernel_variant & ~HEVCDBK_MAP_MASK) == HEVCDBK_KERNEL_PACKED);
+            for (unsigned i = 0; i < n_planes && fused; i++) {
+                sbs[i] = (int)planes[i].sample_bytes;
+                fused = (i == 0 || planes[i].is_chroma) && dbk_packed_supports(args[i], sbs[i], planes[i].is_chroma != 0);
+            }
+            fused = fused && dbk_multi_supports(args.data(), (int)n_planes, sbs);
+            if (fused || n_planes == 1) {
+                dbk_set_next_launch_events(ctx->timed_events[2 * s], ctx->timed_events[2 * s + 1]);
+                const int rc = launch_planes(ctx, planes, args.data(), n_planes, kernel_variant, ctx->compute);
+                dbk_set_next_launch_events(nullptr, nullptr);
+                if (rc) return rc;
+                continue;
+            }
+        }
         for (unsigned i = 0; i < n_planes; i++) {
             dbk_set_next_launch_events(i == 0 ? ctx->timed_events[2 * s] : nullptr,
                                        i + 1 == n_planes ? ctx->timed_events[2 * s + 1] : nullptr);

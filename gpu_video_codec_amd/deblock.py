@@ -325,6 +325,13 @@ class Context:
         _chk(_lib.lib().hevc_sao_filter_device(self.handle, C.byref(planes), params_ptr, params_stride, params_frame_stride,
                                                ctb_log2, keep_ptr, keep_stride, keep_frame_stride, None), self.handle)
 
+    def filter_device_planes(self, planes_list, qp, *, tc_table=None, beta_table=None, variant=KERNEL_AUTO):
+        """hevc_deblocking_filter_device_planes: Y, U, V of a batch in one call (one fused launch where that applies)."""
+        arr = (_lib.DevicePlanes * len(planes_list))(*planes_list)
+        t, _k = _tables(tc_table, beta_table)
+        _chk(_lib.lib().hevc_deblocking_filter_device_planes(self.handle, arr, len(planes_list), int(qp),
+                                                             None if t is None else C.byref(t), variant, None), self.handle)
+
     def run_timed(self, planes_list, qp, steps, *, variant=KERNEL_AUTO, tc_table=None, beta_table=None):
         """`steps` back-to-back launches of every plane in planes_list; per-step kernel ms (HIP events)."""
         arr = (_lib.DevicePlanes * len(planes_list))(*planes_list)

@@ -190,6 +190,14 @@ HEVCDBK_API int hevc_deblocking_filter_device(hevcdbk_context *ctx, const hevcdb
                                   unsigned qp, const hevcdbk_tables *tables, int kernel_variant,
                                   void *hip_stream /* NULL => the context's compute stream */);
 
+/* The planes of a batch of frames in ONE call -- normally Y, U, V of a 4:2:0 batch (planes[0] luma; 1 <= n_planes <= 3; all
+ * with the same n_frames).  Replaces the reference's three launches per frame (gpu.cu:1266-1285): when every plane is 8 bit
+ * with a scalar QP (the reference's case) they go out as ONE fused launch, whatever the frame size; other operands are
+ * launched plane by plane, exactly as n_planes calls of hevc_deblocking_filter_device would.  Same bytes either way. */
+HEVCDBK_API int hevc_deblocking_filter_device_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *planes,
+                                         unsigned n_planes, unsigned qp, const hevcdbk_tables *tables,
+                                         int kernel_variant, void *hip_stream);
+
 /* ---- device memory / stream plumbing for hosts without a HIP binding (ctypes, cgo, JNI) ---- */
 HEVCDBK_API int hevcdbk_device_malloc(hevcdbk_context *ctx, size_t bytes, void **dptr);
 HEVCDBK_API int hevcdbk_device_free(hevcdbk_context *ctx, void *dptr);

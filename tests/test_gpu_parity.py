@@ -390,6 +390,50 @@ def test_row_major_mapping_forced(ctx, oracle):
     b.free()
 
 
+def test_device_planes_one_call_large_frames(ctx, oracle):
+    """hevc_deblocking_filter_device_planes: Y, U, V of a batch of LARGE 4:2:0 frames in one call (one fused launch for 8-bit
+    scalar-QP planes, SURVEY 8f rank 1, no frame-size gate), and the operands the fused kernel does not take (10 bit, a QP
+    map) through the same entry, plane by plane: same bytes as the oracle plane by plane."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    for (w, h, n, bd) in [(3840, 144, 2, 8), (1920, 1088, 2, 8), (7680, 48, 1, 8), (1280, 72, 3, 10)]:
+        ys = np.stack([synth.blocky_plane(w, h, seed=10 + f, bit_depth=bd) for f in range(n)])
+        us = np.stack([synth.blocky_plane(w // 2, h // 2, seed=20 + f, bit_depth=bd, dc_range=4) for f in range(n)])
+        vs = np.stack([synth.blocky_plane(w // 2, h // 2, seed=30 + f, bit_depth=bd, dc_range=4) for f in range(n)])
+        for variant in (_lib.KERNEL_AUTO, _lib.KERNEL_GENERIC):
+            bat = []
+            for a, ch in ((ys, False), (us, True), (vs, True)):
+                b = deblock.DeviceBatch(ctx, a.shape[2], a.shape[1], n, bit_depth=bd, is_chroma=ch)
+                b.upload_all(a)
+                bat.append(b)
+            ctx.filter_device_planes([b.planes() for b in bat], 35, variant=variant)
+            ctx.synchronize()
+            for b, a, ch in zip(bat, (ys, us, vs), (False, True, True)):
+                for f in range(n):
+                    assert np.array_equal(b.download_frame(f), oracle.filter_plane(a[f], 35, is_chroma=ch, bit_depth=bd)), (w, h, bd, variant, ch, f)
+                b.free()
+    # a QP map on the luma plane: not fusable, still one call
+    w, h = 1920, 136
+    y = synth.blocky_plane(w, h, seed=3)
+    u = synth.blocky_plane(w // 2, h // 2, seed=4, dc_range=4)
+    qmap = np.random.default_rng(5).integers(22, 45, ((h + 63) // 64, (w + 63) // 64)).astype(np.uint8)
+    by = deblock.DeviceBatch(ctx, w, h, 1)
+    by.upload_all(y[None])
+    by.set_qp_map(qmap)
+    bu = deblock.DeviceBatch(ctx, w // 2, h // 2, 1, is_chroma=True)
+    bu.upload_all(u[None])
+    bu.set_qp_map(qmap)
+    ctx.filter_device_planes([by.planes(), bu.planes()], 30)
+    ctx.synchronize()
+    assert np.array_equal(by.download_frame(0), oracle.filter_plane(y, 30, qp_map=qmap))
+    assert np.array_equal(bu.download_frame(0), oracle.filter_plane(u, 30, qp_map=qmap, is_chroma=True))
+    by.free()
+    bu.free()
+    # argument errors
+    with pytest.raises(deblock.DeblockError) as e:
+        ctx.filter_device_planes([], 30)
+    assert e.value.code == _lib.ERR_ARG
+
+
 _DIAG_CHILD = r"""
 import sys
 sys.path.insert(0, %(root)r)
@@ -709,8 +753,9 @@ def test_packed_16bit_chroma_kernel(ctx, oracle):
 
 def test_file_operator_sharded_over_workers(ctx, oracle, tmp_path):
     """hevcdbk_filter_yuv_file_multi (SURVEY 8e inside the C ABI): chunks of the file go round-robin to worker threads, each
-    with its own context.  Only one GPU is visible here, so the workers share device 0 -- the sharding, offsets and
-    ownership logic are exactly what G devices run.  Output must equal the single-context operator's byte for byte."""
+    with its own context.  The device lists enumerate hevcdbk_device_count(): on a one-GPU box the workers share device 0
+    -- the sharding, offsets and ownership logic are exactly what G devices run -- and on an 8-GPU node every real device
+    filters its share.  Output must equal the single-context operator's byte for byte."""
     from gpu_video_codec_amd import deblock, synth
     w, h, n = 352, 288, 150
     frames = [oracle.join_yuv420(*synth.blocky_yuv420(w, h, seed=500 + i)) for i in range(n)]
@@ -722,8 +767,11 @@ def test_file_operator_sharded_over_workers(ctx, oracle, tmp_path):
     fb = w * h * 3 // 2
     for i in (0, 63, 64, 149):
         assert want[i * fb:(i + 1) * fb] == oracle.filter_yuv420(frames[i], w, h, 34), i
-    for devices in ([0], [0, 0], [0, 0, 0, 0, 0]):
-        out = tmp_path / ("multi%d.yuv" % len(devices))
+    ndev = deblock.device_count()
+    every = list(range(ndev))              # one worker per REAL device of the box (1 on the test box, 8 on a node)
+    twice = every + every[::-1]            # and each device driven by two workers
+    for devices in ([0], [0, 0], [0, 0, 0, 0, 0], every, twice):
+        out = tmp_path / ("multi%d_%d.yuv" % (len(devices), devices[-1]))
         got_n, wall = deblock.filter_yuv_file_multi(devices, str(src), str(out), w, h, 34)
         assert got_n == n and wall > 0
         assert out.read_bytes() == want, devices
