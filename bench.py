@@ -299,9 +299,9 @@ def main():
     ap.add_argument("--variant", choices=["auto", "generic", "packed", "copy"], default="auto",
                     help="copy = diagnostic memory-path ablation (dst = src, no filter), runs on libhevcdbk_diag.so; "
                          "never a benchmark result")
-    ap.add_argument("--map", choices=["auto", "rows", "linear", "stripe"], default="auto",
-                    help="block -> lane map of the packed kernels (HEVCDBK_MAP_*; same bytes either way; stripe = the "
-                         "experimental persistent-wave map of libhevcdbk_diag.so, never a result)")
+    ap.add_argument("--map", choices=["auto", "rows", "linear", "tiles", "stripe"], default="auto",
+                    help="block -> lane map of the packed kernels (HEVCDBK_MAP_*; same bytes either way; stripe / tiles = the "
+                         "experimental persistent-wave and LDS-tile maps of libhevcdbk_diag.so, never a result)")
     ap.add_argument("--diag", default=None,
                     help="load libhevcdbk_diag.so and set these knobs (csrc/hevcdbk_diag.h): A/B runs only, never a result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -331,13 +331,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    if args.map == "stripe" and args.diag is None:
-        args.diag = ""   # the stripe map lives in the diagnostic library only
+    if args.map in ("stripe", "tiles") and args.diag is None:
+        args.diag = ""   # the stripe and tile maps live in the diagnostic library only
     if args.variant == "copy" or args.diag is not None:
         _lib.use_diagnostic_library(args.diag)
     variant = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "packed": _lib.KERNEL_PACKED,
                "copy": _lib.DIAG_KERNEL_COPY}[args.variant]
-    variant |= {"auto": _lib.MAP_AUTO, "rows": _lib.MAP_ROWS, "linear": _lib.MAP_LINEAR, "stripe": _lib.DIAG_MAP_STRIPE}[args.map]
+    variant |= {"auto": _lib.MAP_AUTO, "rows": _lib.MAP_ROWS, "linear": _lib.MAP_LINEAR, "tiles": _lib.DIAG_MAP_TILES, "stripe": _lib.DIAG_MAP_STRIPE}[args.map]
     w, h, F, bd = args.width, args.height, args.frames, args.bit_depth
     sb = 1 if bd == 8 else 2
     ndev = deblock.device_count()

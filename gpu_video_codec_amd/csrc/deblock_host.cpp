@@ -198,13 +198,13 @@ int launch(hevcdbk_context *ctx, const DbkArgs &a0, int sample_bytes, bool chrom
     const int map = variant & HEVCDBK_MAP_MASK;
     variant &= ~HEVCDBK_MAP_MASK;
     #ifdef HEVCDBK_DIAG
-    if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR && map != HEVCDBK_DIAG_MAP_STRIPE) return HEVCDBK_ERR_ARG;
+    if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR && map != HEVCDBK_DIAG_MAP_TILES && map != HEVCDBK_DIAG_MAP_STRIPE) return HEVCDBK_ERR_ARG;
 #else
     if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR) return HEVCDBK_ERR_ARG;
 #endif
     DbkArgs a = a0;
     a.n_cus = ctx->n_cus;
-    a.map_override = map == HEVCDBK_MAP_ROWS ? 1 : (map == HEVCDBK_MAP_LINEAR ? 2 : (map == 0x300 ? 3 : 0));
+    a.map_override = map == HEVCDBK_MAP_ROWS ? 1 : (map == HEVCDBK_MAP_LINEAR ? 2 : (map == 0x300 ? 3 : (map == 0x400 ? 4 : 0)));
 #ifdef HEVCDBK_DIAG
     if (variant == HEVCDBK_DIAG_KERNEL_COPY) {
         if (!dbk_packed_supports(a, sample_bytes, chroma)) return HEVCDBK_ERR_UNSUPPORTED;

@@ -27,10 +27,18 @@ struct DbkArgs {
     uint32_t magic_wpf, magic_nbx;  /* floor(2^32/d)+1 reciprocals */
     int xcd_swizzle;                /* renumber workgroups so each XCD gets a contiguous range */
     int map_override;               /* block -> lane map of the packed kernels: 0 = chosen from the geometry, 1 = one
-                                       workgroup per block row, 2 = row-major numbering (HEVCDBK_MAP_* of the C ABI); 3 = stripes,
-                                       diagnostic build only (HEVCDBK_DIAG_MAP_STRIPE) */
+                                       workgroup per block row, 2 = row-major numbering (HEVCDBK_MAP_* of the C ABI); 3 = stripes, 4 = LDS tiles:
+                                       diagnostic build only (HEVCDBK_DIAG_MAP_STRIPE / _TILES) */
     int n_cus;                      /* compute units of the device (0 = unknown: 256) */
 #ifdef HEVCDBK_DIAG /* the diagnostic build only (libhevcdbk_diag.so, hevcdbk_diag.h): never in the product library */
+    /* tile map of the 8-bit luma kernel (dbk_tile_kernel; filled by dbk_launch_packed): a workgroup stages k whole block
+     * rows in LDS with naturally aligned 16-byte-per-lane accesses and filters the blocks bx = 1..nbx-1 out of LDS */
+    int tl_k;                       /* block rows per workgroup */
+    int tl_M;                       /* blocks per row handled: nbx - 1 */
+    int tl_nw;                      /* waves per workgroup: ceil(k*M / 64) */
+    int tl_cw;                      /* 16-byte pieces per pixel row: plane_w / 16 */
+    int tl_ndma;                    /* 1-KiB transfers per tile: 8*k*plane_w / 1024 */
+    uint32_t tl_magic_M, tl_magic_cw;
     /* stripe map of the 8-bit luma kernel (dbk_stripe_kernel; filled by dbk_launch_packed): the blocks bx = 1..nbx-1 of
      * the block rows 1..nby-2 are dealt to persistent one-wave workgroups that walk down the frames, the frame border
      * (row 0, row nby-1, column 0) goes to extra workgroups of the same launch */

@@ -660,6 +660,126 @@ __global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiAr
 
 #ifdef HEVCDBK_DIAG
 /* ------------------------------------------------------------------------------------------ */
+/* 8-bit luma, scalar QP: the TILE map -- whole block rows staged in LDS, aligned 16-byte accesses */
+/* DIAGNOSTIC BUILD ONLY (bit-exact; measured slower than the plain maps on MI355X, DESIGN.md 4.1: its two workgroup barriers
+ * put the 15 waves of a workgroup into the same phase, and the CU's VALU idles while they load or store).
+ *
+ * The plain maps read and write each lane's 8-byte row pieces directly: a wave's row span starts 4 bytes before an 8-byte
+ * boundary (offset blocks start at x = 8*bx - 4), every 128-byte line at a span end is shared by two waves, and an access
+ * is 8 bytes per lane -- measured ceiling of that pattern 5.5-5.8 TB/s against 6.0 for plain 16-byte-per-lane copies.
+ * Here a workgroup owns k WHOLE block rows (4K: k = 2, 15 waves):
+ *   1. the 8k pixel rows travel HBM -> LDS as naturally aligned 1-KiB transfers (buffer_load_dwordx4 ... lds, 16 bytes per
+ *      lane, no VGPRs, no VALU): every 128-byte line is touched by exactly one instruction of one wave;
+ *   2. after a barrier each lane takes its 8x8 offset block out of LDS (two dwords per row at a 4-byte-aligned address --
+ *      the 4-byte skew of the offset-block grid is absorbed HERE instead of on the memory bus), filters it in registers
+ *      exactly as the plain kernel does, and puts it back;
+ *   3. after a second barrier the rows go LDS -> HBM as aligned 16-byte-per-lane stores.
+ * Blocks: bx = 1..nbx-1 of every block row, numbered row-major inside the workgroup (t = rowb*M + bx - 1, M = nbx - 1), so
+ * k*M = a multiple of 64 leaves no lane idle (the row map idles 31 of 512 lanes at 4K).  Out-of-image pixel rows of the
+ * first / last block row are zero-filled in LDS (the reference's zero padding, cpu.h:55-71) and never stored.  The column
+ * bx = 0 (left half outside the image) is left untouched by this kernel -- its bytes x = 0..3 are stored back as loaded --
+ * and filtered by dbk_col0_kernel in a second, tiny launch behind it.
+ */
+template <int MODE> /* 0 = filter; 1 = copy (diagnostic build only) */
+__global__ __launch_bounds__(1024) void dbk_tile_kernel(const DbkArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tl[]; /* 8k rows x plane_w bytes, + 16 bytes of slack */
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    lds_u8 *const tl_lds = (lds_u8 *)tl;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t k = (uint32_t)a.tl_k, M = (uint32_t)a.tl_M, nw = (uint32_t)a.tl_nw, cw = (uint32_t)a.tl_cw;
+    const uint32_t ndma = (uint32_t)a.tl_ndma, Wb = (uint32_t)a.plane_w, H = (uint32_t)a.plane_h, pitch = (uint32_t)a.pitch;
+    const uint32_t f = blockIdx.y, by0 = blockIdx.x * k;
+    const int y0 = (int)by0 * 8 - 4;                                     /* first pixel row of the tile, -4 for by0 == 0 */
+    const uint32_t rows_here = ((uint32_t)a.nby - by0) < k ? ((uint32_t)a.nby - by0) : k;
+    const uint32_t plane_bytes = pitch * H;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.src) + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        a.dst + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
+
+    /* this lane's block: bS bytes first (register-returning loads: the compiler places their waits, which must not be
+     * behind the LDS-DMA it does not count) */
+    const uint32_t t = w * 64u + lane;
+    const uint32_t rowb = __umulhi(t, a.tl_magic_M);
+    const uint32_t bx = 1u + t - rowb * M;
+    const bool act = rowb < rows_here;
+    const int by = (int)(by0 + rowb);
+    dbk::BlockBs bs;
+    if constexpr (MODE == 0) bs = load_bs_buffer<true>(a, (int)f, by, (int)bx, act);
+
+    /* pixel rows outside the image (tiles of block row 0 and nby-1): zeros in LDS */
+    const bool edge_tile = y0 < 0 || (uint32_t)(y0 + 8 * (int)k) > H;
+    if (edge_tile) {
+        for (uint32_t c = threadIdx.x; c < ndma * 64u; c += blockDim.x) {
+            const uint32_t row = __umulhi(c, a.tl_magic_cw);
+            if ((uint32_t)(y0 + (int)row) >= H) *reinterpret_cast<uint4 *>(tl + 16u * c) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    /* HBM -> LDS: transfer i = 64 consecutive 16-byte pieces of the tile (row-major), dealt round-robin to the waves */
+    for (uint32_t i = w; i < ndma; i += nw) {
+        const uint32_t c = 64u * i + lane;
+        const uint32_t row = __umulhi(c, a.tl_magic_cw), col = c - row * cw;
+        const uint32_t y = (uint32_t)(y0 + (int)row);
+        if (y < H) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, tl_lds + 1024u * i, 16, y * pitch + 16u * col, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    /* LDS -> registers: row r of the block = bytes 8*bx-4 .. 8*bx+3 of tile row 8*rowb + r */
+    const uint32_t base = act ? (rowb * 8u) * Wb + bx * 8u - 4u : 0u;
+    const bool redge = bx == M;                                          /* bx == nbx-1: right half outside the image */
+    uint32_t L[8], R[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        L[r] = *reinterpret_cast<const uint32_t *>(tl + base + (uint32_t)r * Wb);
+        R[r] = *reinterpret_cast<const uint32_t *>(tl + base + (uint32_t)r * Wb + 4u);
+    }
+    if (__builtin_amdgcn_ballot_w64(redge) != 0ull) {
+        if (redge) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) R[r] = 0u; /* the bytes read there are the next row's first four */
+        }
+    }
+    if constexpr (MODE == 0) {
+        const dbk::BlockQp qp = block_qp<false, false>(a, (int)f, 0, 0);
+        dbk::packed_filter_block<false>(L, R, bs, qp);
+    }
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<uint32_t *>(tl + base + (uint32_t)r * Wb) = L[r];
+        if (!redge) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) *reinterpret_cast<uint32_t *>(tl + base + (uint32_t)r * Wb + 4u) = R[r];
+        }
+    }
+    __syncthreads();
+
+    /* LDS -> HBM, the same 1-KiB transfers; rows outside the image are not stored */
+    for (uint32_t i = w; i < ndma; i += nw) {
+        const uint32_t c = 64u * i + lane;
+        const uint32_t row = __umulhi(c, a.tl_magic_cw), col = c - row * cw;
+        const uint32_t y = (uint32_t)(y0 + (int)row);
+        const uint4 v = *reinterpret_cast<const uint4 *>(tl + 16u * c);
+        u32x4 q;
+        q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+        __builtin_amdgcn_raw_buffer_store_b128(q, rd, y < H ? y * pitch + 16u * col : kOob, 0, 0);
+    }
+}
+
+/* the column bx = 0 the tile kernel leaves out: one lane = one block (by = lane index inside the frame), per-lane path */
+template <int MODE>
+__global__ __launch_bounds__(64) void dbk_col0_kernel(const DbkArgs a)
+{
+    const int by = (int)(blockIdx.x * 64u + threadIdx.x);
+    packed_body<false, MODE, false, 2, false>(a, by < a.nby ? by : 0, (int)blockIdx.y, 0, by < a.nby, 0);
+}
+
+#endif /* HEVCDBK_DIAG: tile map */
+
+#ifdef HEVCDBK_DIAG
+/* ------------------------------------------------------------------------------------------ */
 /* 8-bit luma, scalar QP: the STRIPE map -- persistent waves, the next tile prefetched into LDS  */
 /* DIAGNOSTIC BUILD ONLY (measured slower than the plain maps on MI355X; bit-exact, kept for A/B runs).
  *
@@ -1317,6 +1437,43 @@ static bool plan_stripe(const DbkArgs &a, DbkArgs &b, int sample_bytes, bool chr
 
 #endif /* HEVCDBK_DIAG */
 
+#ifdef HEVCDBK_DIAG
+/* the tile map (dbk_tile_kernel + dbk_col0_kernel): 8-bit luma, scalar QP, whole planes whose rows are whole 128-byte
+ * lines; fills the tl_* fields of `b`, the grid's x size and the dynamic LDS size */
+static bool plan_tile(const DbkArgs &a, DbkArgs &b, int sample_bytes, bool chroma, unsigned &grid_x, size_t &lds)
+{
+    if (sample_bytes != 1 || chroma || a.qp_map || a.by_count != 0 || a.max_v != 255) return false;
+    if (a.plane_w % 128 != 0 || a.pitch % 16 != 0 || a.frame_stride % 16 != 0 || ((uintptr_t)a.src % 16) != 0 ||
+        ((uintptr_t)a.dst % 16) != 0 || a.nby < 2)
+        return false;
+    const long long M = a.nbx - 1;
+    /* k block rows per workgroup: at most 16 waves and 64 KiB of LDS (two workgroups per CU), fewest idle lanes */
+    int k = 0;
+    double best = 2.0;
+    for (int c = 1; c <= 8; c++) {
+        const long long waves = (c * M + 63) / 64;
+        if (waves > 16 || 8ll * c * a.plane_w + 16 > 65536) break;
+        const double waste = (double)(waves * 64 - c * M) / (double)(waves * 64);
+        if (waste + 1e-9 < best) { best = waste; k = c; }
+    }
+    if (k == 0) return false;
+    const long long nw = (k * M + 63) / 64, cw = a.plane_w / 16, ndma = 8ll * k * a.plane_w / 1024;
+    if ((nw * 64) * M >= (1ll << 32) || (ndma * 64 + 1024) * cw >= (1ll << 32)) return false;
+    auto magic = [](long long d) { return (uint32_t)((1ull << 32) / (unsigned long long)d + 1ull); }; /* d >= 2 */
+    b.tl_k = k;
+    b.tl_M = (int)M;
+    b.tl_nw = (int)nw;
+    b.tl_cw = (int)cw;
+    b.tl_ndma = (int)ndma;
+    b.tl_magic_M = magic(M);
+    b.tl_magic_cw = magic(cw);
+    grid_x = (unsigned)((a.nby + k - 1) / k);
+    lds = (size_t)(8ll * k * a.plane_w + 16);
+    return true;
+}
+
+#endif /* HEVCDBK_DIAG */
+
 hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, int mode, hipStream_t stream)
 {
     if (a.n_frames <= 0 || a.nbx <= 0 || a.nby <= 0) return hipSuccess;
@@ -1327,6 +1484,27 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
     b.diag_dummy = g_dbk_diag.dummy;
     b.use_queue = g_dbk_diag.queue;
     b.diag_xshift = (mode == 1 && g_dbk_diag.align) ? 4 * sample_bytes : 0;
+#endif
+#ifdef HEVCDBK_DIAG
+    if (a.map_override == 4) { /* HEVCDBK_DIAG_MAP_TILES */
+        unsigned gx = 0;
+        size_t lds = 0;
+        const DbkArgs b0 = b;
+        if (plan_tile(b0, b, sample_bytes, chroma, gx, lds)) {
+            const dim3 grid(gx, (unsigned)b.n_frames, 1), block(64u * (unsigned)b.tl_nw, 1, 1), cgrid(((unsigned)b.nby + 63u) / 64u, (unsigned)b.n_frames, 1);
+            hipEvent_t s_ = t_next_start, e_ = t_next_stop; /* two launches: the first stamps the start, the second the stop */
+            t_next_start = t_next_stop = nullptr;
+            if (mode == 1) {
+                hipExtLaunchKernelGGL((dbk_tile_kernel<1>), grid, block, lds, stream, s_, nullptr, 0, b);
+                hipExtLaunchKernelGGL((dbk_col0_kernel<1>), cgrid, dim3(64), 0, stream, nullptr, e_, 0, b);
+            } else {
+                hipExtLaunchKernelGGL((dbk_tile_kernel<0>), grid, block, lds, stream, s_, nullptr, 0, b);
+                hipExtLaunchKernelGGL((dbk_col0_kernel<0>), cgrid, dim3(64), 0, stream, nullptr, e_, 0, b);
+            }
+            return hipGetLastError();
+        }
+        b = b0;
+    }
 #endif
 #ifdef HEVCDBK_DIAG
     if (a.map_override == 3) { /* HEVCDBK_DIAG_MAP_STRIPE */

@@ -21,6 +21,10 @@ extern "C" {
  * (8-bit luma, scalar QP, width a multiple of 128; other operands take the geometry's own map).  Bit-exact; measured
  * SLOWER than the plain maps on MI355X, which is why it is not in the product. */
 #define HEVCDBK_DIAG_MAP_STRIPE 0x300
+/* likewise: whole block rows staged in LDS by a workgroup (naturally aligned 16-byte-per-lane LDS-DMA in, aligned 16-byte
+ * stores out, blocks filtered out of LDS between two barriers, column bx = 0 by a second tiny launch); 8-bit luma, scalar
+ * QP, width a multiple of 128.  Bit-exact; measured SLOWER than the plain maps. */
+#define HEVCDBK_DIAG_MAP_TILES 0x400
 
 /* comma-separated knobs, process-wide, replacing the previous set (NULL or "" = defaults):
  *   wg=N      workgroup width cap of the packed kernels (64..1024, default 512)

@@ -395,7 +395,7 @@ def test_device_planes_one_call_large_frames(ctx, oracle):
     scalar-QP planes, SURVEY 8f rank 1, no frame-size gate), and the operands the fused kernel does not take (10 bit, a QP
     map) through the same entry, plane by plane: same bytes as the oracle plane by plane."""
     from gpu_video_codec_amd import deblock, synth, _lib
-    for (w, h, n, bd) in [(3840, 144, 2, 8), (1920, 1088, 2, 8), (7680, 48, 1, 8), (1280, 72, 3, 10)]:
+    for (w, h, n, bd) in [(3840, 144, 2, 8), (1920, 1088, 2, 8), (7680, 48, 1, 8), (1280, 80, 3, 10)]:
         ys = np.stack([synth.blocky_plane(w, h, seed=10 + f, bit_depth=bd) for f in range(n)])
         us = np.stack([synth.blocky_plane(w // 2, h // 2, seed=20 + f, bit_depth=bd, dc_range=4) for f in range(n)])
         vs = np.stack([synth.blocky_plane(w // 2, h // 2, seed=30 + f, bit_depth=bd, dc_range=4) for f in range(n)])
@@ -412,7 +412,7 @@ def test_device_planes_one_call_large_frames(ctx, oracle):
                     assert np.array_equal(b.download_frame(f), oracle.filter_plane(a[f], 35, is_chroma=ch, bit_depth=bd)), (w, h, bd, variant, ch, f)
                 b.free()
     # a QP map on the luma plane: not fusable, still one call
-    w, h = 1920, 136
+    w, h = 1920, 144
     y = synth.blocky_plane(w, h, seed=3)
     u = synth.blocky_plane(w // 2, h // 2, seed=4, dc_range=4)
     qmap = np.random.default_rng(5).integers(22, 45, ((h + 63) // 64, (w + 63) // 64)).astype(np.uint8)
@@ -463,25 +463,27 @@ with deblock.Context(0) as ctx:
     # per group 1..8, a last group that is not full, fewer items than persistent workgroups and many more, in place,
     # per-frame random bS (every guard), a QP with tc = 0; operands it does not take fall back to the geometry's own map
     rng = np.random.default_rng(4242)
-    variant = _lib.KERNEL_PACKED | _lib.DIAG_MAP_STRIPE
-    for (w, h, n) in [(3840, 72, 2), (3840, 136, 3), (1920, 264, 2), (1280, 72, 5), (512, 40, 3), (128, 24, 2), (256, 136, 40),
-                      (4096, 48, 1), (7680, 40, 1), (1024, 1032, 3)]:
-        fr = np.stack([synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30))) for _ in range(min(n, 4))])
-        fr = np.concatenate([fr] * (n // len(fr) + 1))[:n].copy()
-        fr[0, : h // 2, : w // 3] = rng.integers(0, 256, (h // 2, w // 3), dtype=np.uint8)
-        if n > 1:
-            fr[1] = fr[1][::-1]
-        bss = [oracle.lcg_bs(w, h, 5 + f) if f % 2 == 0 else oracle.default_bs(w, h) for f in range(n)]
-        for qp, in_place in ((37, False), (32, True), (17, False)):
-            got = run_batch(ctx, fr, qp, variant=variant, bs=bss, in_place=in_place)
-            for f in sorted({0, 1 % n, n // 2, n - 1}):
-                assert np.array_equal(got[f], oracle.filter_plane(fr[f], qp, vert_bs=bss[f][0], hor_bs=bss[f][1])), (w, h, n, qp, f)
-    y = synth.blocky_plane(520, 72, seed=3)
-    assert np.array_equal(run_batch(ctx, y[None], 37, variant=variant)[0], oracle.filter_plane(y, 37))
-    c = synth.blocky_plane(1920, 136, seed=4)
-    assert np.array_equal(run_batch(ctx, c[None], 40, variant=variant, is_chroma=True)[0], oracle.filter_plane(c, 40, is_chroma=True))
-    t = synth.blocky_plane(1920, 72, seed=5, bit_depth=10)
-    assert np.array_equal(run_batch(ctx, t[None], 32, variant=variant, bit_depth=10)[0], oracle.filter_plane(t, 32, bit_depth=10))
+    for variant in (_lib.KERNEL_PACKED | _lib.DIAG_MAP_STRIPE, _lib.KERNEL_PACKED | _lib.DIAG_MAP_TILES):
+        # ... and the tile map (HEVCDBK_DIAG_MAP_TILES): whole block rows staged in LDS, blocks filtered out of LDS, column
+        # bx = 0 by the second launch; 1..8 block rows per workgroup, a last workgroup that is not full, one-block-row heights
+        for (w, h, n) in [(3840, 72, 2), (3840, 136, 3), (1920, 264, 2), (1280, 72, 5), (512, 40, 3), (128, 8, 2), (128, 24, 2),
+                          (256, 136, 40), (4096, 48, 1), (7680, 40, 1), (1024, 1032, 3), (384, 16, 3)]:
+            fr = np.stack([synth.blocky_plane(w, h, seed=int(rng.integers(1, 1 << 30))) for _ in range(min(n, 4))])
+            fr = np.concatenate([fr] * (n // len(fr) + 1))[:n].copy()
+            fr[0, : h // 2, : w // 3] = rng.integers(0, 256, (h // 2, w // 3), dtype=np.uint8)
+            if n > 1:
+                fr[1] = fr[1][::-1]
+            bss = [oracle.lcg_bs(w, h, 5 + f) if f % 2 == 0 else oracle.default_bs(w, h) for f in range(n)]
+            for qp, in_place in ((37, False), (32, True), (17, False)):
+                got = run_batch(ctx, fr, qp, variant=variant, bs=bss, in_place=in_place)
+                for f in sorted({0, 1 %% n, n // 2, n - 1}):
+                    assert np.array_equal(got[f], oracle.filter_plane(fr[f], qp, vert_bs=bss[f][0], hor_bs=bss[f][1])), (w, h, n, qp, f)
+        y = synth.blocky_plane(520, 72, seed=3)
+        assert np.array_equal(run_batch(ctx, y[None], 37, variant=variant)[0], oracle.filter_plane(y, 37))
+        c = synth.blocky_plane(1920, 136, seed=4)
+        assert np.array_equal(run_batch(ctx, c[None], 40, variant=variant, is_chroma=True)[0], oracle.filter_plane(c, 40, is_chroma=True))
+        t = synth.blocky_plane(1920, 72, seed=5, bit_depth=10)
+        assert np.array_equal(run_batch(ctx, t[None], 32, variant=variant, bit_depth=10)[0], oracle.filter_plane(t, 32, bit_depth=10))
 print("DIAG-OK")
 """
 

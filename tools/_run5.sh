@@ -1,14 +1,18 @@
 set -e
 O=gpurun_out/r02; mkdir -p $O
-B="timeout -k 10 300 python bench.py --no-e2e --no-cpu-baseline --no-extra --steps 50 --settle 30"
-for k in dummy=0 dummy=16 dummy=24 dummy=24,align; do
-  $B --variant copy --map stripe --diag $k 2>$O/g.err | python3 -c "
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "tile_map or device_planes or sharded" > $O/pytest_gpu_e.txt 2>&1 || { tail -40 $O/pytest_gpu_e.txt; exit 1; }
+tail -2 $O/pytest_gpu_e.txt
+B="timeout -k 10 300 python bench.py --no-e2e --no-cpu-baseline --no-extra --steps 100 --settle 50"
+$B --variant copy --map tiles 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('copy $k', round(d['roofline']['kernel_avg_ms'],4))"
-done
-for k in dummy=0 dummy=16; do
-$B --map stripe --diag $k | python3 -c "
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('copy tiles', round(d['roofline']['kernel_avg_ms'],4), d['bit_exact_vs_oracle'])"
+$B --variant copy 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('filter stripe $k', round(d['roofline']['kernel_avg_ms'],4), d['bit_exact_vs_oracle'])"
-done
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('copy rows', round(d['roofline']['kernel_avg_ms'],4), d['bit_exact_vs_oracle'])"
+$B --map tiles | python3 -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('filter tiles', round(d['roofline']['kernel_avg_ms'],4), d['bit_exact_vs_oracle'], round(d['roofline']['frac'],4))"
+$B | python3 -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('filter rows', round(d['roofline']['kernel_avg_ms'],4), d['bit_exact_vs_oracle'], round(d['roofline']['frac'],4))"
 echo ALLDONE
