@@ -473,7 +473,7 @@ with deblock.Context(0) as ctx:
             fr[0, : h // 2, : w // 3] = rng.integers(0, 256, (h // 2, w // 3), dtype=np.uint8)
             if n > 1:
                 fr[1] = fr[1][::-1]
-            bss = [oracle.lcg_bs(w, h, 5 + f) if f % 2 == 0 else oracle.default_bs(w, h) for f in range(n)]
+            bss = [oracle.lcg_bs(w, h, 5 + f) if f %% 2 == 0 else oracle.default_bs(w, h) for f in range(n)]
             for qp, in_place in ((37, False), (32, True), (17, False)):
                 got = run_batch(ctx, fr, qp, variant=variant, bs=bss, in_place=in_place)
                 for f in sorted({0, 1 %% n, n // 2, n - 1}):
