@@ -176,6 +176,32 @@ def reference_table_line(ctx, threads_all, reps=30):
     return out
 
 
+def live_traffic(w, h, F, bd, timeout_s=240):
+    """HBM bytes per launch measured IN THIS RUN: tools/hbm_traffic.py's four rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE, each alone, on the diagnostic copy variant for the calibration and on the product kernel) as child
+    processes of a parent that has not touched the GPU yet.  None if rocprofv3 is missing or a pass fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    out = tempfile.mkdtemp(prefix="hbm_traffic_")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "hbm_traffic.py"), "--tag", "live", "--frames", str(F), "--width", str(w),
+           "--height", str(h), "--bit-depth", str(bd), "--outdir", out, "--no-profiles-copy"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        if r.returncode != 0:
+            return None
+        with open(os.path.join(out, "live_hbm_traffic.json")) as fh:
+            t = json.load(fh)
+        return (t["hbm_bytes_per_launch"], "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                "calibrated on the copy variant (read x%.3f, write x%.3f)" % (t["calibration"]["read_corr"], t["calibration"]["write_corr"]))
+    except (OSError, ValueError, KeyError, subprocess.TimeoutExpired):
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def measured_traffic(w, h, F, bd):
     """HBM bytes per launch from the PMC counters (tools/hbm_traffic.py: separate FETCH_SIZE / WRITE_SIZE
     passes, calibrated on the diagnostic copy variant), taken from the newest committed
@@ -304,6 +330,9 @@ def main():
                          "experimental persistent-wave and LDS-tile maps of libhevcdbk_diag.so, never a result)")
     ap.add_argument("--diag", default=None,
                     help="load libhevcdbk_diag.so and set these knobs (csrc/hevcdbk_diag.h): A/B runs only, never a result")
+    ap.add_argument("--traffic", choices=["live", "file", "none"], default="live",
+                    help="roofline.traffic: live = PMC passes (rocprofv3) run as child processes before this process touches "
+                         "the GPU (about 20 s); file = newest matching profiles/*_hbm_traffic.json; live falls back to file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and the reference table line")
@@ -331,6 +360,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    w, h, F, bd = args.width, args.height, args.frames, args.bit_depth
+    traffic = None
+    if world == 1 and args.variant in ("auto", "packed") and args.diag is None and args.map == "auto":
+        if args.traffic == "live":
+            traffic = live_traffic(w, h, F, bd)   # BEFORE the first HIP call of this process
+        if traffic is None and args.traffic in ("live", "file"):
+            traffic = measured_traffic(w, h, F, bd)
     if args.map in ("stripe", "tiles") and args.diag is None:
         args.diag = ""   # the stripe and tile maps live in the diagnostic library only
     if args.variant == "copy" or args.diag is not None:
@@ -338,7 +374,6 @@ def main():
     variant = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "packed": _lib.KERNEL_PACKED,
                "copy": _lib.DIAG_KERNEL_COPY}[args.variant]
     variant |= {"auto": _lib.MAP_AUTO, "rows": _lib.MAP_ROWS, "linear": _lib.MAP_LINEAR, "tiles": _lib.DIAG_MAP_TILES, "stripe": _lib.DIAG_MAP_STRIPE}[args.map]
-    w, h, F, bd = args.width, args.height, args.frames, args.bit_depth
     sb = 1 if bd == 8 else 2
     ndev = deblock.device_count()
     if ndev <= 0:
@@ -377,7 +412,6 @@ def main():
     value = world * F * args.steps / elapsed
     abytes = algorithmic_bytes_per_frame(w, h, sb) * F
     roof = roofline_of(kernel_ms, abytes)
-    traffic = measured_traffic(w, h, F, bd) if args.variant in ("auto", "packed") else None
     roof["traffic"] = traffic[0] if traffic else None
     roof["traffic_source"] = traffic[1] if traffic else None
     roof["read_GBps"] = (abytes - w * h * sb * F) / (roof["kernel_avg_ms"] * 1e-3) / 1e9

@@ -3,7 +3,7 @@ O=gpurun_out/r02
 mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "stripe or row_major or diagnostic" > $O/pytest_gpu_c.txt 2>&1 || { tail -40 $O/pytest_gpu_c.txt; exit 1; }
 tail -2 $O/pytest_gpu_c.txt
-B="timeout -k 10 300 python bench.py --no-e2e --no-cpu-baseline --no-extra"
+B="timeout -k 10 300 python bench.py --traffic none --no-e2e --no-cpu-baseline --no-extra"
 $B > $O/e_rows.json 2>/dev/null
 $B --map stripe > $O/e_stripe.json 2>$O/e_stripe.err
 $B --variant copy > $O/e_copy_rows.json 2>/dev/null

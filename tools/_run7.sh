@@ -1,7 +1,10 @@
 set -e
 O=gpurun_out/r02; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_h265.py -m gpu -x -q -k "sao" > $O/pytest_gpu_g.txt 2>&1 || { tail -40 $O/pytest_gpu_g.txt; exit 1; }
-tail -2 $O/pytest_gpu_g.txt
-python tools/bench_sao.py
-python tools/bench_sao.py --bit-depth 10
+( time python bench.py > $O/i_full.json 2> $O/i_full.err ) 2> $O/i_full.time
+tail -3 $O/i_full.time
+python3 - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/r02/i_full.json") if l.startswith("{")][-1])
+print(d["roofline"])
+PY
 echo ALLDONE

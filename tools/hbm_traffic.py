@@ -30,7 +30,8 @@ def run_pmc(counter, variant, frames, outdir, steps=3, extra=()):
     d = os.path.join(outdir, "%s_%s" % (counter, variant))
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1",
-           "--variant", variant, "--frames", str(frames), "--no-cpu-baseline", "--no-e2e", "--no-extra"] + list(extra)
+           "--variant", variant, "--frames", str(frames), "--no-cpu-baseline", "--no-e2e", "--no-extra", "--traffic", "none",
+           "--settle", "5"] + list(extra)
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     vals = []
@@ -51,6 +52,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--outdir", default=os.path.join(ROOT, "gpurun_out", "traffic"))
+    ap.add_argument("--no-profiles-copy", action="store_true", help="write the result to --outdir only (bench.py --traffic live)")
     args = ap.parse_args()
     os.makedirs(args.outdir, exist_ok=True)
     w, h, F = args.width, args.height, args.frames
@@ -77,7 +79,9 @@ def main():
     out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
     path = os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % args.tag)
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    for p in (path, os.path.join(args.outdir, os.path.basename(path))):  # gpurun only returns gpurun_out/
+    targets = [os.path.join(args.outdir, os.path.basename(path))] if args.no_profiles_copy else \
+        [path, os.path.join(args.outdir, os.path.basename(path))]  # gpurun only returns gpurun_out/
+    for p in targets:
         with open(p, "w") as fh:
             json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))
