@@ -1,11 +1,12 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence ON the GPU box (one gpurun call):
-#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r01'
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02'
 # Kernel-trace + stats runs and PMC runs are separate rocprofv3 invocations (never --pmc with a trace domain), and the
 # profiled program is python3 itself.  Everything lands in gpurun_out/profiles_<tag>/; copy what should be judged into
-# profiles/<tag>/.
+# profiles/<tag>/.  The bench runs under the profiler take `--traffic file`: the default (`live`) starts rocprofv3 PMC
+# children of its own, which must not nest inside another rocprofv3.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -20,26 +21,38 @@ run_stats() { # name, then the python script and its arguments
     echo "== $name"; cat "$OUT/kernel_stats_$name.csv"
 }
 
-run_stats bench_default_1gpu "$R/bench.py"
-run_stats bench_8k10_1gpu "$R/bench.py" --width 7680 --height 4320 --bit-depth 10 --frames 48
+run_stats bench_default_1gpu "$R/bench.py" --traffic file
+run_stats bench_8k10_1gpu "$R/bench.py" --traffic none --no-extra --width 7680 --height 4320 --bit-depth 10 --frames 32
 run_stats bench_h265 "$R/tools/bench_h265.py"
-run_stats e2e_small "$R/tools/e2e_small.py" --file-frames 300 --sequence-frames 256
-run_stats bench_yuv420 "$R/tools/bench_yuv420.py"
+run_stats e2e_small "$R/tools/e2e_small.py" --file-frames 300 --sequence-frames 512
 run_stats bench_sao "$R/tools/bench_sao.py"
 python3 - "$OUT" <<'PY'
 import csv, json, sys
 out = sys.argv[1]
-rows = [r for r in csv.DictReader(open(out + "/kernel_trace_bench_default_1gpu.csv")) if "dbk_packed" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(out + "/kernel_trace_bench_default_1gpu.csv")) if "dbk_packed_kernel" in r["Kernel_Name"]]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in rows]
 n = len(d)
-res = {"source": "rocprofv3 --kernel-trace of `python3 bench.py` (100 settle + 3 warm-up + 200 timed launches, plus the spot check / e2e launches)",
-       "dispatches": n, "avg_all_ms": sum(d) / n, "avg_first_100_ms": sum(d[:100]) / 100, "avg_launches_104_to_303_ms": sum(d[103:303]) / 200,
-       "min_ms": min(d), "max_ms": max(d)}
+res = {"source": "rocprofv3 --kernel-trace of `python3 bench.py --traffic file` (100 settle + 3 warm-up + 200 timed launches of the luma kernel, then the extra configs / spot checks / e2e launches)",
+       "dispatches_of_the_luma_kernel": n, "avg_first_100_ms": sum(d[:100]) / 100, "avg_launches_104_to_303_ms": sum(d[103:303]) / 200,
+       "min_ms": min(d[103:303]), "max_ms": max(d[103:303])}
 json.dump(res, open(out + "/kernel_trace_phases_packed_bench.json", "w"), indent=1)
+# the raw rows of the timed window, as the profiler wrote them
+with open(out + "/kernel_trace_timed_window.csv", "w", newline="") as fh:
+    wtr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+    wtr.writeheader()
+    for r in rows[103:303]:
+        wtr.writerow(r)
 print(json.dumps(res))
 PY
 python3 "$R/tools/hbm_traffic.py" --tag "$TAG" > "$OUT/hbm_traffic.log" 2>&1
-python3 "$R/tools/hbm_traffic.py" --tag "${TAG}_8k10" --width 7680 --height 4320 --bit-depth 10 --frames 48 >> "$OUT/hbm_traffic.log" 2>&1
+python3 "$R/tools/hbm_traffic.py" --tag "${TAG}_8k10" --width 7680 --height 4320 --bit-depth 10 --frames 32 >> "$OUT/hbm_traffic.log" 2>&1
 cp "$R"/gpurun_out/traffic/*_hbm_traffic.json "$OUT/" 2>/dev/null || true
-rm -rf "$OUT"/bench_default_1gpu "$OUT"/bench_8k10_1gpu "$OUT"/bench_h265 "$OUT"/e2e_small "$OUT"/bench_yuv420 "$OUT"/bench_sao "$OUT"/kernel_trace_*.csv
+python3 "$R/tools/sq_counters.py" --tag packed_4k8 > "$OUT/sq_counters_packed_4k8.log" 2>&1 || true
+python3 "$R/tools/sq_counters.py" --tag copy_4k8 --variant copy > "$OUT/sq_counters_copy_4k8.log" 2>&1 || true
+cp "$R"/gpurun_out/sq/packed_4k8.json "$OUT/sq_counters_packed_4k8.json" 2>/dev/null || true
+cp "$R"/gpurun_out/sq/copy_4k8.json "$OUT/sq_counters_copy_4k8.json" 2>/dev/null || true
+python3 "$R/tools/clock_trace.py" 300 packed > "$OUT/clock_trace_packed_4k8.txt" 2>&1 || true
+"$R/tools/ubench/valu_rate" > "$OUT/ubench_valu_rate.txt" 2>&1 || true
+"$R/tools/ubench/copy_bw" > "$OUT/ubench_copy_bw.txt" 2>&1 || true
+rm -rf "$OUT"/bench_default_1gpu "$OUT"/bench_8k10_1gpu "$OUT"/bench_h265 "$OUT"/e2e_small "$OUT"/bench_sao "$OUT"/kernel_trace_bench_*.csv "$OUT"/kernel_trace_e2e_small.csv
 ls -la "$OUT"
