@@ -161,19 +161,32 @@ struct SaoRow {
     uint32_t rO0, rO1;       /* (s2, s4), (s6, s8): right neighbours of O0, O1 */
 };
 
-template <bool HALO>
+typedef uint32_t sao_u32x4 __attribute__((ext_vector_type(4), aligned(4))); /* 16 bytes at a 4-byte-aligned address */
+
+/* HALO: the neighbours to the left / right take part.  INNER (wave-uniform): every lane's 16 bytes x-4 .. x+11 lie inside
+ * the row, so the row is ONE 16-byte load per lane; otherwise three loads with the halo positions moved inside the row */
+template <bool HALO, bool INNER>
 __device__ __forceinline__ SaoRow sao_load_row(const uint8_t *row, int x, int w)
 {
-    const uint2 c = *reinterpret_cast<const uint2 *>(row + x);
+    uint32_t lh = 0u, rh = 0u;
+    uint2 c;
+    if constexpr (HALO && INNER) {
+        const sao_u32x4 q = *reinterpret_cast<const sao_u32x4 *>(row + x - 4);
+        lh = q.x; c.x = q.y; c.y = q.z; rh = q.w;
+    } else {
+        c = *reinterpret_cast<const uint2 *>(row + x);
+        if constexpr (HALO) {
+            /* positions outside the row read a valid dword of the row instead; the border masks discard what comes of it */
+            lh = *reinterpret_cast<const uint32_t *>(row + (x >= 4 ? x - 4 : 0));
+            rh = *reinterpret_cast<const uint32_t *>(row + (x + 12 <= w ? x + 8 : w - 4));
+        }
+    }
     SaoRow r;
     r.E0 = __builtin_amdgcn_perm(c.x, c.x, 0x0c020c00u);
     r.O0 = __builtin_amdgcn_perm(c.x, c.x, 0x0c030c01u);
     r.E1 = __builtin_amdgcn_perm(c.y, c.y, 0x0c020c00u);
     r.O1 = __builtin_amdgcn_perm(c.y, c.y, 0x0c030c01u);
     if constexpr (HALO) {
-        /* positions outside the row read a valid dword of the row instead; the border masks discard what comes of it */
-        const uint32_t lh = *reinterpret_cast<const uint32_t *>(row + (x >= 4 ? x - 4 : 0));
-        const uint32_t rh = *reinterpret_cast<const uint32_t *>(row + (x + 12 <= w ? x + 8 : w - 4));
         r.lE0 = __builtin_amdgcn_perm(c.x, lh, 0x0c050c03u);  /* (lh.b3, c.x.b1) */
         r.lE1 = __builtin_amdgcn_perm(c.y, c.x, 0x0c050c03u); /* (c.x.b3, c.y.b1) */
         r.rO0 = __builtin_amdgcn_perm(c.y, c.x, 0x0c040c02u); /* (c.x.b2, c.y.b0) */
@@ -215,16 +228,16 @@ __device__ __forceinline__ void sao8_edge_block(const DbkSaoArgs &a, const uint8
     const bool vertical = cls != 0;   /* neighbours in the rows above / below take part */
     SaoRow up, mid, dn;
     if (horizontal) {
-        up = sao_load_row<true>(row_at(y0 - 1), x, a.plane_w);
-        mid = sao_load_row<true>(row_at(y0), x, a.plane_w);
+        up = sao_load_row<true, !BORDER>(row_at(y0 - 1), x, a.plane_w);
+        mid = sao_load_row<true, !BORDER>(row_at(y0), x, a.plane_w);
     } else {
-        up = sao_load_row<false>(row_at(y0 - 1), x, a.plane_w);
-        mid = sao_load_row<false>(row_at(y0), x, a.plane_w);
+        up = sao_load_row<false, false>(row_at(y0 - 1), x, a.plane_w);
+        mid = sao_load_row<false, false>(row_at(y0), x, a.plane_w);
     }
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int y = y0 + r;
-        dn = horizontal ? sao_load_row<true>(row_at(y + 1), x, a.plane_w) : sao_load_row<false>(row_at(y + 1), x, a.plane_w);
+        dn = horizontal ? sao_load_row<true, !BORDER>(row_at(y + 1), x, a.plane_w) : sao_load_row<false, false>(row_at(y + 1), x, a.plane_w);
         uint32_t i0, i1, i2, i3; /* indices of E0, O0, E1, O1 */
         if (cls == 0) {          /* (-1, 0) / (1, 0) */
             i0 = sao_edge_idx(mid.E0, mid.lE0, mid.O0);
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(256) void sao8_kernel(const DbkSaoArgs a)
         };
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const SaoRow m = sao_load_row<false>(src + (long long)(y0 + r) * a.pitch, x, a.plane_w);
+            const SaoRow m = sao_load_row<false, false>(src + (long long)(y0 + r) * a.pitch, x, a.plane_w);
             uint2 out;
             out.x = band(m.E0) | (band(m.O0) << 8);
             out.y = band(m.E1) | (band(m.O1) << 8);
