@@ -348,7 +348,9 @@ class DeviceBatch:
     This is the layout bench.py times: frame f at base + f*frame_stride, tight pitch."""
 
     def __init__(self, ctx, plane_w, plane_h, n_frames, *, bit_depth=8, sample_bytes=None, is_chroma=False,
-                 in_place=False, per_frame_bs=True, pitch=None):
+                 in_place=False, per_frame_bs=True, pitch=None, storage=None):
+        """storage = (src_buffer, dst_buffer) of another batch: lay this batch out in that device memory instead of
+        allocating (a decoder's frame pool serving another geometry); free() then leaves those buffers alone."""
         self.ctx = ctx
         self.w, self.h, self.n = plane_w, plane_h, n_frames
         self.bit_depth = bit_depth
@@ -358,8 +360,13 @@ class DeviceBatch:
         self.pitch = plane_w * self.sb if pitch is None else int(pitch)  # bytes; > width*sb leaves row padding
         assert self.pitch >= plane_w * self.sb and self.pitch % self.sb == 0
         self.frame_bytes = self.pitch * plane_h
-        self.src = ctx.alloc(self.frame_bytes * n_frames)
-        self.dst = self.src if in_place else ctx.alloc(self.frame_bytes * n_frames)
+        self._borrowed = storage is not None
+        if storage is not None:
+            self.src, self.dst = storage
+            assert self.src.nbytes >= self.frame_bytes * n_frames and self.dst.nbytes >= self.frame_bytes * n_frames
+        else:
+            self.src = ctx.alloc(self.frame_bytes * n_frames)
+            self.dst = self.src if in_place else ctx.alloc(self.frame_bytes * n_frames)
         self.nv, self.nh = num_vert_bs(plane_w, plane_h), num_hor_bs(plane_w, plane_h)
         self.per_frame_bs = per_frame_bs
         nb = n_frames if per_frame_bs else 1
@@ -421,7 +428,8 @@ class DeviceBatch:
         return a if with_padding else a[:, : self.w]
 
     def free(self):
-        for b in (self.src, self.dst, self.vert, self.hor, self.qp_map):
+        own = (self.vert, self.hor, self.qp_map) if self._borrowed else (self.src, self.dst, self.vert, self.hor, self.qp_map)
+        for b in own:
             if b is not None and b.ptr:
                 b.free()
 
