@@ -658,601 +658,12 @@ __global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiAr
     }
 }
 
-#ifdef HEVCDBK_DIAG
-/* ------------------------------------------------------------------------------------------ */
-/* 8-bit luma, scalar QP: the TILE map -- whole block rows staged in LDS, aligned 16-byte accesses */
-/* DIAGNOSTIC BUILD ONLY (bit-exact; measured slower than the plain maps on MI355X, DESIGN.md 4.1: its two workgroup barriers
- * put the 15 waves of a workgroup into the same phase, and the CU's VALU idles while they load or store).
- *
- * The plain maps read and write each lane's 8-byte row pieces directly: a wave's row span starts 4 bytes before an 8-byte
- * boundary (offset blocks start at x = 8*bx - 4), every 128-byte line at a span end is shared by two waves, and an access
- * is 8 bytes per lane -- measured ceiling of that pattern 5.5-5.8 TB/s against 6.0 for plain 16-byte-per-lane copies.
- * Here a workgroup owns k WHOLE block rows (4K: k = 2, 15 waves):
- *   1. the 8k pixel rows travel HBM -> LDS as naturally aligned 1-KiB transfers (buffer_load_dwordx4 ... lds, 16 bytes per
- *      lane, no VGPRs, no VALU): every 128-byte line is touched by exactly one instruction of one wave;
- *   2. after a barrier each lane takes its 8x8 offset block out of LDS (two dwords per row at a 4-byte-aligned address --
- *      the 4-byte skew of the offset-block grid is absorbed HERE instead of on the memory bus), filters it in registers
- *      exactly as the plain kernel does, and puts it back;
- *   3. after a second barrier the rows go LDS -> HBM as aligned 16-byte-per-lane stores.
- * Blocks: bx = 1..nbx-1 of every block row, numbered row-major inside the workgroup (t = rowb*M + bx - 1, M = nbx - 1), so
- * k*M = a multiple of 64 leaves no lane idle (the row map idles 31 of 512 lanes at 4K).  Out-of-image pixel rows of the
- * first / last block row are zero-filled in LDS (the reference's zero padding, cpu.h:55-71) and never stored.  The column
- * bx = 0 (left half outside the image) is left untouched by this kernel -- its bytes x = 0..3 are stored back as loaded --
- * and filtered by dbk_col0_kernel in a second, tiny launch behind it.
- */
-template <int MODE> /* 0 = filter; 1 = copy (diagnostic build only) */
-__global__ __launch_bounds__(1024) void dbk_tile_kernel(const DbkArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t tl[]; /* 8k rows x plane_w bytes, + 16 bytes of slack */
-    typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    lds_u8 *const tl_lds = (lds_u8 *)tl;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t k = (uint32_t)a.tl_k, M = (uint32_t)a.tl_M, nw = (uint32_t)a.tl_nw, cw = (uint32_t)a.tl_cw;
-    const uint32_t ndma = (uint32_t)a.tl_ndma, Wb = (uint32_t)a.plane_w, H = (uint32_t)a.plane_h, pitch = (uint32_t)a.pitch;
-    const uint32_t f = blockIdx.y, by0 = blockIdx.x * k;
-    const int y0 = (int)by0 * 8 - 4;                                     /* first pixel row of the tile, -4 for by0 == 0 */
-    const uint32_t rows_here = ((uint32_t)a.nby - by0) < k ? ((uint32_t)a.nby - by0) : k;
-    const uint32_t plane_bytes = pitch * H;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t *>(a.src) + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-        a.dst + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
 
-    /* this lane's block: bS bytes first (register-returning loads: the compiler places their waits, which must not be
-     * behind the LDS-DMA it does not count) */
-    const uint32_t t = w * 64u + lane;
-    const uint32_t rowb = __umulhi(t, a.tl_magic_M);
-    const uint32_t bx = 1u + t - rowb * M;
-    const bool act = rowb < rows_here;
-    const int by = (int)(by0 + rowb);
-    dbk::BlockBs bs;
-    if constexpr (MODE == 0) bs = load_bs_buffer<true>(a, (int)f, by, (int)bx, act);
-
-    /* pixel rows outside the image (tiles of block row 0 and nby-1): zeros in LDS */
-    const bool edge_tile = y0 < 0 || (uint32_t)(y0 + 8 * (int)k) > H;
-    if (edge_tile) {
-        for (uint32_t c = threadIdx.x; c < ndma * 64u; c += blockDim.x) {
-            const uint32_t row = __umulhi(c, a.tl_magic_cw);
-            if ((uint32_t)(y0 + (int)row) >= H) *reinterpret_cast<uint4 *>(tl + 16u * c) = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
-    /* HBM -> LDS: transfer i = 64 consecutive 16-byte pieces of the tile (row-major), dealt round-robin to the waves */
-    for (uint32_t i = w; i < ndma; i += nw) {
-        const uint32_t c = 64u * i + lane;
-        const uint32_t row = __umulhi(c, a.tl_magic_cw), col = c - row * cw;
-        const uint32_t y = (uint32_t)(y0 + (int)row);
-        if (y < H) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, tl_lds + 1024u * i, 16, y * pitch + 16u * col, 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    /* LDS -> registers: row r of the block = bytes 8*bx-4 .. 8*bx+3 of tile row 8*rowb + r */
-    const uint32_t base = act ? (rowb * 8u) * Wb + bx * 8u - 4u : 0u;
-    const bool redge = bx == M;                                          /* bx == nbx-1: right half outside the image */
-    uint32_t L[8], R[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        L[r] = *reinterpret_cast<const uint32_t *>(tl + base + (uint32_t)r * Wb);
-        R[r] = *reinterpret_cast<const uint32_t *>(tl + base + (uint32_t)r * Wb + 4u);
-    }
-    if (__builtin_amdgcn_ballot_w64(redge) != 0ull) {
-        if (redge) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) R[r] = 0u; /* the bytes read there are the next row's first four */
-        }
-    }
-    if constexpr (MODE == 0) {
-        const dbk::BlockQp qp = block_qp<false, false>(a, (int)f, 0, 0);
-        dbk::packed_filter_block<false>(L, R, bs, qp);
-    }
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) *reinterpret_cast<uint32_t *>(tl + base + (uint32_t)r * Wb) = L[r];
-        if (!redge) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) *reinterpret_cast<uint32_t *>(tl + base + (uint32_t)r * Wb + 4u) = R[r];
-        }
-    }
-    __syncthreads();
-
-    /* LDS -> HBM, the same 1-KiB transfers; rows outside the image are not stored */
-    for (uint32_t i = w; i < ndma; i += nw) {
-        const uint32_t c = 64u * i + lane;
-        const uint32_t row = __umulhi(c, a.tl_magic_cw), col = c - row * cw;
-        const uint32_t y = (uint32_t)(y0 + (int)row);
-        const uint4 v = *reinterpret_cast<const uint4 *>(tl + 16u * c);
-        u32x4 q;
-        q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
-        __builtin_amdgcn_raw_buffer_store_b128(q, rd, y < H ? y * pitch + 16u * col : kOob, 0, 0);
-    }
-}
-
-/* the column bx = 0 the tile kernel leaves out: one lane = one block (by = lane index inside the frame), per-lane path */
-template <int MODE>
-__global__ __launch_bounds__(64) void dbk_col0_kernel(const DbkArgs a)
-{
-    const int by = (int)(blockIdx.x * 64u + threadIdx.x);
-    packed_body<false, MODE, false, 2, false>(a, by < a.nby ? by : 0, (int)blockIdx.y, 0, by < a.nby, 0);
-}
-
-#endif /* HEVCDBK_DIAG: tile map */
 
 #ifdef HEVCDBK_DIAG
-/* ------------------------------------------------------------------------------------------ */
-/* 8-bit luma, scalar QP: the STRIPE map -- persistent waves, the next tile prefetched into LDS  */
-/* DIAGNOSTIC BUILD ONLY (measured slower than the plain maps on MI355X; bit-exact, kept for A/B runs).
- *
- * Why: with one launch-and-forget wave per 64 blocks (the maps above) a SIMD holds 8 tiles; each is either waiting for its
- * rows, or being filtered, or waiting for its stores.  The filter keeps the VALU ~95 % busy and the row loads and stores
- * keep the memory system ~90 % busy, and with only 8 customers circulating between two nearly saturated servers neither
- * reaches 100 % (measured: removing 7 % of the VALU work bought 1 %).  Here a wave is persistent and owns a STRIPE of the
- * batch: it walks through "items" (one item = one group of k block rows of one frame), and while it filters the tile of
- * item n its tile of item n + Q is already on its way from HBM into the wave's 4 KiB of LDS (buffer_load_dwordx4 ... lds:
- * no VGPRs, no VALU, 16 bytes per lane).  Two tiles per wave are in flight without a single extra register.
- *
- * Tile = 64 consecutive blocks of the row group's row-major numbering t = rowg*M + (bx - 1), M = nbx - 1: the stripes cover
- * bx = 1..nbx-1 of the block rows 1..nby-2 (all 8 pixel rows inside the image, left halves inside the image), so with
- * k*M a multiple of 64 (4K: k = 2 rows, 15 wave slots) no lane idles.  What is left -- block row 0, block row nby-1 and
- * the column bx = 0 -- is the frame border: extra one-wave workgroups at the end of the same grid run it through the
- * per-lane path (PATH 2) of the plain kernel.
- *
- * LDS image of a tile: 8 pixel rows x 512 bytes, lane j's row r at 512*r + 8*j.  One LDS-DMA instruction moves 1 KiB =
- * two pixel rows: lanes 0..31 row 2q, lanes 32..63 row 2q+1, 16 bytes = the blocks 2m, 2m+1 of the tile (M is even, so a
- * pair never straddles a row end).  The workgroup -> (slot, stripe) map keeps the W waves of a row group on one XCD
- * (workgroups are dealt round-robin over the 8 XCDs, an observation used for speed only): neighbouring tiles share the
- * 128-byte line at their common boundary, and the shared reads and the two partial writes then meet in one L2.
- */
-__device__ __forceinline__ uint32_t div_magic(uint32_t x, uint32_t d, uint32_t magic)
-{
-    return d == 1u ? x : __umulhi(x, magic); /* magic = floor(2^32/d) + 1, exact for x < 2^32 / d */
-}
-
-constexpr int kStripeLdsPerWave = 4096 + 256; /* 8 pixel rows x 512 bytes, then 4 x 64 bS bytes */
-
-template <int MODE> /* 0 = filter; 1 = copy (diagnostic build only) */
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void dbk_stripe_kernel(const DbkArgs a)
-{
-    /* one workgroup = the W wave slots of a row group: neighbouring tiles share the 128-byte line at their common boundary,
-     * and with their waves on one CU, working on the same item, the shared reads coalesce and the two partial writes of
-     * such a line meet in the L2 within microseconds (measured: with the slots spread over workgroups that drift apart
-     * the same copy ran 14 % slower) */
-    extern __shared__ __attribute__((aligned(16))) uint8_t tile_all[]; /* W * kStripeLdsPerWave bytes */
-    typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* wave slot inside the row group */
-    uint8_t *const tile = tile_all + w * (uint32_t)kStripeLdsPerWave;
-    lds_u8 *const tile_lds = (lds_u8 *)tile; /* the LDS-DMA destination (M0) */
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t W = (uint32_t)a.st_W, M = (uint32_t)a.st_M, k = (uint32_t)a.st_k, Q = (uint32_t)a.st_Q;
-
-    if (blockIdx.x < (uint32_t)a.st_border_wgs) {
-        /* the frame border, one lane per block; these workgroups come FIRST in the grid so that they run beside the
-         * stripes instead of after them */
-        const uint32_t idx = blockIdx.x * W + w;
-        const uint32_t f = div_magic(idx, (uint32_t)a.st_border_wpf, a.st_magic_bwpf);
-        if (f >= (uint32_t)a.n_frames) return; /* padding wave of the last border workgroup */
-#ifdef HEVCDBK_DIAG
-        if (MODE == 1 && (a.diag_dummy & 8)) return; /* timing experiment: no border */
+/* the measured-and-rejected kernels (LDS queue, stripe map, tile map): diagnostic build only, DESIGN.md 4.1 */
+#include "deblock_diag_kernels.inc"
 #endif
-        const uint32_t u = (idx - f * (uint32_t)a.st_border_wpf) * 64u + lane;
-        const uint32_t nbx = (uint32_t)a.nbx, nby = (uint32_t)a.nby;
-        int by = 0, bx = 0;
-        bool active = true;
-        if (u < nbx) { by = 0; bx = (int)u; }
-        else if (u < 2u * nbx) { by = (int)nby - 1; bx = (int)(u - nbx); }
-        else if (u < 2u * nbx + nby - 2u) { by = 1 + (int)(u - 2u * nbx); bx = 0; }
-        else active = false;
-        packed_body<false, MODE, false, 2, false>(a, by, (int)f, bx, active, 0);
-        return;
-    }
-
-    const uint32_t q = blockIdx.x - (uint32_t)a.st_border_wgs; /* stripe number: items q, q + Q, q + 2Q, ... */
-    const uint32_t n_items = (uint32_t)a.st_items, groups = (uint32_t)a.st_groups;
-    uint32_t item = q;
-    if (item >= n_items) return;
-
-    const uint32_t pitch = (uint32_t)a.pitch;
-    /* this lane's block inside the row group, and the pair of blocks this lane moves by LDS-DMA */
-    const uint32_t t = w * 64u + lane;
-    const uint32_t rowg = __umulhi(t, a.st_magic_M);
-    const uint32_t bx = 1u + t - rowg * M;
-    const uint32_t tp = w * 64u + 2u * (lane & 31u);
-    const uint32_t rowp = __umulhi(tp, a.st_magic_M);
-    const uint32_t bxp = 1u + tp - rowp * M;
-#ifdef HEVCDBK_DIAG /* copy variant, knob "align": every span 4 bytes to the left, i.e. naturally aligned (timing only) */
-    const uint32_t dshift = MODE == 1 ? (uint32_t)a.diag_xshift : 0u;
-#else
-    const uint32_t dshift = 0u;
-#endif
-    const uint32_t voff_dma = (rowp * 8u + (lane >> 5)) * pitch + bxp * 8u - 4u - dshift;
-    const uint32_t voff_dma_idle = (lane >> 5) * pitch + 4u;   /* any valid address: lanes past the group's last row */
-    const uint32_t voff_st = rowg * 8u * pitch + bx * 8u - 4u - dshift;
-    const bool redge = bx == (uint32_t)a.nbx - 1u;             /* right half outside the image */
-    const bool wave_has_redge = __builtin_amdgcn_ballot_w64(redge && rowg < k) != 0ull;
-    const bool hor2_ok = bx < (uint32_t)a.limit_bx;            /* cpu.h:369: only the right-edge block fails */
-
-    /* ONE buffer resource per array for the whole batch (the launcher takes this map only while a batch stays below
-     * 4 GiB): the frame goes into the 32-bit scalar offset, so an item costs a handful of scalar multiplies and no
-     * 64-bit address arithmetic, and the resources never change */
-    const uint32_t fstride = (uint32_t)a.frame_stride;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.src), 0, 0xffffffffu, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, 0xffffffffu, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.vert_bs), 0, 0xffffffffu, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.hor_bs), 0, 0xffffffffu, 0x00020000);
-
-#define DBK_STRIPE_COORDS(it, f_, by0_, rows_)                                                      \
-    const uint32_t f_ = div_magic((it), groups, a.st_magic_groups);                                 \
-    const uint32_t by0_ = 1u + ((it) - f_ * groups) * k;                                            \
-    const uint32_t rows_ = ((uint32_t)a.nby - 1u - by0_) < k ? ((uint32_t)a.nby - 1u - by0_) : k;
-
-    auto issue_dma = [&](uint32_t it) {
-        DBK_STRIPE_COORDS(it, f, by0, rows)
-        const uint32_t v = rowp < rows ? voff_dma : voff_dma_idle;
-        const uint32_t s0 = f * fstride + (by0 * 8u - 4u) * pitch;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, tile_lds + 0, 16, v, s0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, tile_lds + 1024, 16, v, s0 + 2u * pitch, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, tile_lds + 2048, 16, v, s0 + 4u * pitch, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, tile_lds + 3072, 16, v, s0 + 6u * pitch, 0, 0);
-    };
-    /* the bS bytes of the tile's 64 blocks are 64 consecutive bytes of each array per row of the group (two runs in a
-     * tile that straddles rows; M % 16 == 0 keeps a run boundary off the middle of a 16-byte piece): they travel by
-     * LDS-DMA too -- lanes 0..3 ver1 (cpu.h:161), 4..7 ver2 (cpu.h:225) / lanes 0..3 hor1 (cpu.h:289), 4..7 hor2
-     * (cpu.h:370), 16 bytes each -- so that the loop holds no register-returning vector load at all: the compiler does not
-     * count LDS-DMA when it places waits for such loads, and its waits would drain the prefetch. */
-    const uint32_t tb = w * 64u + 16u * (lane & 3u);                 /* first block of this lane's 16-byte piece */
-    const uint32_t rowb = __umulhi(tb, a.st_magic_M), bxb = 1u + tb - rowb * M;
-    /* the buffer range check sees the vector offset alone, so it must not go negative: "the row above" of ver1 sits in
-     * the scalar offset ((by0 - 1) * vstride, by0 >= 1) and ver2 adds a row here */
-    const uint32_t bsv_p = (rowb + ((lane & 4u) ? 1u : 0u)) * (uint32_t)a.vstride + bxb;
-    const uint32_t bsh_p = rowb * (uint32_t)a.hstride + bxb - ((lane & 4u) ? 0u : 1u);                  /* hor1: bx - 1 >= 0 */
-    auto issue_bs_dma = [&](uint32_t it) {
-        DBK_STRIPE_COORDS(it, f, by0, rows)
-        (void)rows;
-        if (lane < 8u) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, tile_lds + 4096, 16, bsv_p,
-                                                     f * (uint32_t)a.vert_bs_stride + (by0 - 1u) * (uint32_t)a.vstride, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, tile_lds + 4224, 16, bsh_p,
-                                                     f * (uint32_t)a.hor_bs_stride + by0 * (uint32_t)a.hstride, 0, 0);
-        }
-    };
-#ifdef HEVCDBK_DIAG /* timing experiments on the copy variant: bit 0 no bS DMA, bit 1 no stores, bit 2 no tile DMA */
-    const int sx = MODE == 1 ? a.diag_dummy : 0;
-#else
-    constexpr int sx = 0;
-#endif
-    auto issue_all = [&](uint32_t it) {
-        if (!(sx & 4)) issue_dma(it);
-        if (!(sx & 1)) issue_bs_dma(it);
-    };
-
-    /* Order of the vector-memory operations of a wave, which is what its vmcnt counts (in issue order):
-     *   tile(n+1) LDS-DMA x4, bS(n+1) LDS-DMA x2  -- issued at the top of item n, before its arithmetic
-     *   stores(n) x8 (x16 in a wave that holds a right-edge block)
-     * so "everything but the stores has arrived" is vmcnt(8 / 16). */
-    issue_all(item);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (;;) {
-        uint32_t L[8], R[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const u32x2 wv = *reinterpret_cast<const u32x2 *>(tile + 512 * r + 8 * lane);
-            L[r] = wv.x;
-            R[r] = wv.y;
-        }
-        DBK_STRIPE_COORDS(item, f, by0, rows)
-        const bool act = rowg < rows;
-        dbk::BlockBs bs; /* by >= 1, by <= nby-2, bx >= 1: the only guard that can fail is hor2's (cpu.h:369) */
-        bs.ver1 = act ? (int)tile[4096 + lane] : 0;
-        bs.ver2 = act ? (int)tile[4160 + lane] : 0;
-        bs.hor1 = act ? (int)tile[4224 + lane] : 0;
-        bs.hor2 = (act && hor2_ok) ? (int)tile[4288 + lane] : 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* tile and bS are in registers: the LDS may be refilled */
-        const uint32_t next = item + Q;
-        const bool has_next = next < n_items;
-        if (has_next) issue_all(next);
-
-        if (wave_has_redge) {
-            if (redge) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) R[r] = 0u; /* the bytes fetched there belong to the next pixel row */
-            }
-        }
-        if constexpr (MODE == 0) {
-            const dbk::BlockQp qp = block_qp<false, false>(a, (int)f, 0, 0);
-            dbk::packed_filter_block<false>(L, R, bs, qp);
-        }
-
-        const uint32_t s0 = f * fstride + (by0 * 8u - 4u) * pitch;
-#ifdef HEVCDBK_DIAG
-        if (a.diag_dummy & 16) __builtin_amdgcn_s_barrier(); /* experiment: the row group's waves store together */
-#endif
-        if (sx & 2) {
-            if (L[0] == 0x12345678u && R[7] == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b32(L[3] ^ R[5], rd, kOob, 0, 0);
-        } else if (wave_has_redge) {
-            const uint32_t vfull = (act && !redge) ? voff_st : kOob, vhalf = (act && redge) ? voff_st : kOob;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                u32x2 wv;
-                wv.x = L[r];
-                wv.y = R[r];
-                __builtin_amdgcn_raw_buffer_store_b64(wv, rd, vfull, s0 + (uint32_t)r * pitch, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, vhalf, s0 + (uint32_t)r * pitch, 0);
-            }
-        } else {
-            const uint32_t vfull = act ? voff_st : kOob;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                u32x2 wv;
-                wv.x = L[r];
-                wv.y = R[r];
-                __builtin_amdgcn_raw_buffer_store_b64(wv, rd, vfull, s0 + (uint32_t)r * pitch, 0);
-            }
-        }
-        if (!has_next) break;
-        item = next;
-        /* the next tile and its bS bytes were requested BEFORE this item's stores: wait for everything but the stores */
-        if (sx & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (wave_has_redge) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    }
-#undef DBK_STRIPE_COORDS
-}
-
-#endif /* HEVCDBK_DIAG: stripe map */
-
-#ifdef HEVCDBK_DIAG /* measured and rejected; kept in the diagnostic build for A/B runs */
-/* ------------------------------------------------------------------------------------------ */
-/* 8-bit luma with workgroup-level scheduling of the strong filter                              */
-/*
- * Why: strong (cpu.h:1128-1213) and normal (cpu.h:1215-1357) segments are mixed in every wave, so the
- * plain kernel executes both paths for all 64 lanes; with either path removed it sits at the memory floor
- * (DESIGN.md 4.1).  Here a lane that decides "strong" does not filter: it appends its 16 tap registers to
- * a queue in LDS; after a workgroup barrier the queue is drained by consecutive lanes of the whole
- * workgroup (strong path at ~100 % lane utilisation instead of ~26 %), a second barrier, and the owners
- * read their 12 changed registers back.  Three stages follow the data dependences: ver1+ver2 (independent
- * of each other), hor1, hor2.  A segment that does not fit the queue is filtered inline (same result).
- *
- * LDS: one array, two queue regions used alternately (stage V and H2 -> region 0, H1 -> region 1; a wave
- * can only reach the H2 push after every wave has finished reading stage V back) + three tail counters.
- * Each region is 4 planes of uint4 (structure of arrays: consecutive slots are consecutive 16-byte words,
- * conflict-free for ds_read/write_b128):
- *   plane 0 = a.p0,a.p1,a.p2,a.q0   plane 1 = a.q1,a.q2,b.p0,b.p1   plane 2 = b.p2,b.q0,b.q1,b.q2
- *   plane 3 = a.p3,a.q3,b.p3,b.q3 (read-only inputs, never written back)
- */
-/* queue capacities per workgroup width WG (threads): stage V pushes up to 2*WG candidates, H1/H2 up to WG;
- * sized for ~36 % / 50 % strong, overflow is filtered inline.  WG=512: 39,952 B (4 workgroups per CU). */
-template <int WG> struct QCaps {
-    static constexpr int cap0 = WG * 23 / 32, cap1 = WG / 2;
-    static constexpr int words = 4 * (cap0 + cap1) + 1; /* uint4 words incl. the counters */
-};
-
-struct QRegion {
-    uint4 *mem;
-    int cap;
-    unsigned *tail;
-};
-
-__device__ __forceinline__ void q_store_all(const QRegion &q, unsigned slot, const dbk::Taps &a, const dbk::Taps &b)
-{
-    using dbk::pk_bits;
-    q.mem[0 * q.cap + slot] = make_uint4(pk_bits(a.p0), pk_bits(a.p1), pk_bits(a.p2), pk_bits(a.q0));
-    q.mem[1 * q.cap + slot] = make_uint4(pk_bits(a.q1), pk_bits(a.q2), pk_bits(b.p0), pk_bits(b.p1));
-    q.mem[2 * q.cap + slot] = make_uint4(pk_bits(b.p2), pk_bits(b.q0), pk_bits(b.q1), pk_bits(b.q2));
-    q.mem[3 * q.cap + slot] = make_uint4(pk_bits(a.p3), pk_bits(a.q3), pk_bits(b.p3), pk_bits(b.q3));
-}
-__device__ __forceinline__ void q_store_results(const QRegion &q, unsigned slot, const dbk::Taps &a, const dbk::Taps &b)
-{
-    using dbk::pk_bits;
-    q.mem[0 * q.cap + slot] = make_uint4(pk_bits(a.p0), pk_bits(a.p1), pk_bits(a.p2), pk_bits(a.q0));
-    q.mem[1 * q.cap + slot] = make_uint4(pk_bits(a.q1), pk_bits(a.q2), pk_bits(b.p0), pk_bits(b.p1));
-    q.mem[2 * q.cap + slot] = make_uint4(pk_bits(b.p2), pk_bits(b.q0), pk_bits(b.q1), pk_bits(b.q2));
-}
-__device__ __forceinline__ void q_load_results(const QRegion &q, unsigned slot, dbk::Taps &a, dbk::Taps &b)
-{
-    using dbk::bits_pk;
-    const uint4 w0 = q.mem[0 * q.cap + slot], w1 = q.mem[1 * q.cap + slot], w2 = q.mem[2 * q.cap + slot];
-    a.p0 = bits_pk(w0.x); a.p1 = bits_pk(w0.y); a.p2 = bits_pk(w0.z); a.q0 = bits_pk(w0.w);
-    a.q1 = bits_pk(w1.x); a.q2 = bits_pk(w1.y); b.p0 = bits_pk(w1.z); b.p1 = bits_pk(w1.w);
-    b.p2 = bits_pk(w2.x); b.q0 = bits_pk(w2.y); b.q1 = bits_pk(w2.z); b.q2 = bits_pk(w2.w);
-}
-__device__ __forceinline__ void q_load_all(const QRegion &q, unsigned slot, dbk::Taps &a, dbk::Taps &b)
-{
-    using dbk::bits_pk;
-    q_load_results(q, slot, a, b);
-    const uint4 w3 = q.mem[3 * q.cap + slot];
-    a.p3 = bits_pk(w3.x); a.q3 = bits_pk(w3.y); b.p3 = bits_pk(w3.z); b.q3 = bits_pk(w3.w);
-}
-
-/* one stage: NS segments per lane (A[s], B[s] = pair A / pair B taps, on[s] = bS says "filter") */
-template <int NS>
-__device__ __forceinline__ void q_stage(dbk::Taps (&A)[NS], dbk::Taps (&B)[NS], const bool (&on)[NS], int beta, int tc,
-                                        const QRegion &q, int lane)
-{
-    bool strong[NS];
-    unsigned slot[NS];
-    unsigned wave_cnt = 0;
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        strong[s] = false;
-        if (on[s]) {
-            const dbk::Decision d = dbk::decide(A[s], beta, tc);
-            if (d.filter) {
-                if (d.strong) strong[s] = true;
-                else dbk::normal_pairs(A[s], B[s], tc, dbk::mask_of(d.cond5), dbk::mask_of(d.cond6), 255);
-            }
-        }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(strong[s]);
-        slot[s] = wave_cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        wave_cnt += (unsigned)__builtin_popcountll(m);
-    }
-    /* one LDS atomic per wave reserves a contiguous run of slots */
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(q.tail, wave_cnt);
-    base = __builtin_amdgcn_readfirstlane(base);
-    const dbk::pk c = dbk::splat(2 * tc);
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        slot[s] += base;
-        if (strong[s]) {
-            if (slot[s] < (unsigned)q.cap) {
-                q_store_all(q, slot[s], A[s], B[s]);
-            } else { /* queue full: filter here (rare; same arithmetic) */
-                dbk::strong_pair(A[s], c);
-                dbk::strong_pair(B[s], c);
-                strong[s] = false;
-            }
-        }
-    }
-    __syncthreads();
-    {   /* drain: lane tid of the workgroup takes queue entry tid */
-        unsigned total = *q.tail;
-        if (total > (unsigned)q.cap) total = (unsigned)q.cap;
-        for (unsigned e = threadIdx.x; e < total; e += blockDim.x) {
-            dbk::Taps ta, tb;
-            q_load_all(q, e, ta, tb);
-            dbk::strong_pair(ta, c);
-            dbk::strong_pair(tb, c);
-            q_store_results(q, e, ta, tb);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-        if (strong[s]) q_load_results(q, slot[s], A[s], B[s]);
-}
-
-template <bool NT, bool LINEAR, int WG>
-__global__ __launch_bounds__(WG) void dbk_packed_q_kernel(const DbkArgs a)
-{
-    constexpr int kQCap0 = QCaps<WG>::cap0, kQCap1 = QCaps<WG>::cap1, kQWords = QCaps<WG>::words;
-    __shared__ __attribute__((aligned(16))) uint4 smem[kQWords];
-    unsigned *tails = reinterpret_cast<unsigned *>(&smem[kQWords - 1]);
-    if (threadIdx.x < 3) tails[threadIdx.x] = 0u;
-
-    WaveCoords c;
-    if (!wave_coords<LINEAR>(a, c)) return; /* workgroup-uniform */
-    const int lane = (int)(threadIdx.x & 63u);
-    const int f = c.f, by = c.by, bx = c.bx;
-    const bool active = c.active;
-    const bool lv = active && bx > 0, rv = active && bx < a.nbx - 1;
-    const int y0 = by * 8 - 4;
-    const uint32_t xoff = (uint32_t)(bx * 8 - 4);
-    const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t *>(a.src) + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-        a.dst + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
-
-    uint32_t L[8], R[8];
-    dbk::BlockBs bs;
-    if (c.interior) {
-        const int by_s = __builtin_amdgcn_readfirstlane(by);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, (by_s * 8 - 4 + r) * (int)a.pitch, aux_bits<NT>());
-            L[r] = w.x;
-            R[r] = w.y;
-        }
-        bs = load_bs_buffer<false>(a, f, by_s, bx, true);
-    } else {
-        const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
-            const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
-            L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
-            R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && rv) ? off + 4u : kOob, 0, aux_bits<NT>());
-        }
-        bs = load_bs_buffer<true>(a, f, by, bx, active);
-    }
-
-    const QRegion q0{smem, kQCap0, &tails[0]};
-    const QRegion q1{smem + 4 * kQCap0, kQCap1, &tails[1]};
-    const QRegion q2{smem, kQCap0, &tails[2]};
-    __syncthreads(); /* counters zeroed before the first push */
-
-    using dbk::Taps;
-    using dbk::pick_hi;
-    using dbk::pick_lo;
-    /* stage V: ver1 and ver2 (cpu.h:159-284) */
-    Taps VA[2] = {dbk::unpack_ver(L[0], L[3], R[0], R[3]), dbk::unpack_ver(L[4], L[7], R[4], R[7])};
-    Taps VB[2] = {dbk::unpack_ver(L[1], L[2], R[1], R[2]), dbk::unpack_ver(L[5], L[6], R[5], R[6])};
-    {
-        const bool on[2] = {bs.ver1 > 0, bs.ver2 > 0};
-        q_stage<2>(VA, VB, on, a.beta, a.tc, q0, lane);
-    }
-    const Taps &va1 = VA[0], &vb1 = VB[0], &va2 = VA[1], &vb2 = VB[1];
-
-    /* stage H1 (cpu.h:287-365); register re-pairing as in dbk::luma_block_core */
-    Taps HA[1], HB[1];
-    Taps &ha = HA[0], &hb = HB[0];
-    ha.p0 = pick_hi(va1.p3, va1.p0); hb.p0 = pick_hi(va1.p2, va1.p1);
-    ha.p1 = pick_hi(vb1.p3, vb1.p0); hb.p1 = pick_hi(vb1.p2, vb1.p1);
-    ha.p2 = pick_lo(vb1.p3, vb1.p0); hb.p2 = pick_lo(vb1.p2, vb1.p1);
-    ha.p3 = pick_lo(va1.p3, va1.p0); hb.p3 = pick_lo(va1.p2, va1.p1);
-    ha.q0 = pick_lo(va2.p3, va2.p0); hb.q0 = pick_lo(va2.p2, va2.p1);
-    ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1);
-    ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1);
-    ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1);
-    {
-        const bool on[1] = {bs.hor1 > 0};
-        q_stage<1>(HA, HB, on, a.beta, a.tc, q1, lane);
-    }
-
-    /* stage H2 (cpu.h:368-446) */
-    Taps GA[1], GB[1];
-    Taps &ga = GA[0], &gb = GB[0];
-    ga.p0 = pick_hi(va1.q0, va1.q3); gb.p0 = pick_hi(va1.q1, va1.q2);
-    ga.p1 = pick_hi(vb1.q0, vb1.q3); gb.p1 = pick_hi(vb1.q1, vb1.q2);
-    ga.p2 = pick_lo(vb1.q0, vb1.q3); gb.p2 = pick_lo(vb1.q1, vb1.q2);
-    ga.p3 = pick_lo(va1.q0, va1.q3); gb.p3 = pick_lo(va1.q1, va1.q2);
-    ga.q0 = ha.q0; ga.q1 = ha.q1; ga.q2 = ha.q2; ga.q3 = ha.q3;
-    gb.q0 = hb.q0; gb.q1 = hb.q1; gb.q2 = hb.q2; gb.q3 = hb.q3;
-    {
-        const bool on[1] = {bs.hor2 > 0};
-        q_stage<1>(GA, GB, on, a.beta, a.tc, q2, lane);
-    }
-
-    /* final pack (as dbk::packed_filter_luma_block) */
-    using dbk::row_of;
-    using dbk::perm;
-    using dbk::pk_bits;
-    L[0] = row_of(ha.p3, hb.p3); L[1] = row_of(ha.p2, hb.p2); L[2] = row_of(ha.p1, hb.p1); L[3] = row_of(ha.p0, hb.p0);
-    L[4] = row_of(ga.q0, gb.q0); L[5] = row_of(ga.q1, gb.q1); L[6] = row_of(ga.q2, gb.q2); L[7] = row_of(ga.q3, gb.q3);
-    R[0] = row_of(ga.p3, gb.p3); R[1] = row_of(ga.p2, gb.p2); R[2] = row_of(ga.p1, gb.p1); R[3] = row_of(ga.p0, gb.p0);
-    {
-        const uint32_t u1 = perm(pk_bits(va2.q1), pk_bits(va2.q0), 0x06020400u);
-        const uint32_t u2 = perm(pk_bits(va2.q3), pk_bits(va2.q2), 0x06020400u);
-        R[4] = perm(u2, u1, 0x05040100u);
-        R[7] = perm(u2, u1, 0x07060302u);
-        const uint32_t w1 = perm(pk_bits(vb2.q1), pk_bits(vb2.q0), 0x06020400u);
-        const uint32_t w2 = perm(pk_bits(vb2.q3), pk_bits(vb2.q2), 0x06020400u);
-        R[5] = perm(w2, w1, 0x05040100u);
-        R[6] = perm(w2, w1, 0x07060302u);
-    }
-
-    if (c.interior) {
-        const int by_s = __builtin_amdgcn_readfirstlane(by);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            u32x2 w;
-            w.x = L[r];
-            w.y = R[r];
-            __builtin_amdgcn_raw_buffer_store_b64(w, rd, xoff, (by_s * 8 - 4 + r) * (int)a.pitch, aux_bits<NT>());
-        }
-    } else {
-        const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
-            const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
-            __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
-            __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, (yv && rv) ? off + 4u : kOob, 0, aux_bits<NT>());
-        }
-    }
-}
-
-#endif /* HEVCDBK_DIAG */
 
 } /* namespace */
 
