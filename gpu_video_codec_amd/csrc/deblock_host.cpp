@@ -898,13 +898,20 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
             const auto wall0 = std::chrono::steady_clock::now();
             auto stage = [&](unsigned g0, size_t k, uint8_t *c, bool in) {
                 for (size_t i = 0; i < k; i++)
-                    for (int p = 0; p < 3; p++)
-                        for (unsigned r = 0; r < ph[p]; r++) {
-                            uint8_t *cp = c + i * fb + poff[p] + (size_t)r * pw[p];
-                            uint8_t *fp = (uint8_t *)frames[g0 + i].plane[p] + r * frames[g0 + i].pitch[p];
-                            if (in) std::memcpy(cp, fp, pw[p]);
-                            else std::memcpy(fp, cp, pw[p]);
+                    for (int p = 0; p < 3; p++) {
+                        uint8_t *cp = c + i * fb + poff[p];
+                        uint8_t *fp = (uint8_t *)frames[g0 + i].plane[p];
+                        const size_t pitch = frames[g0 + i].pitch[p];
+                        if (pitch == pw[p]) { /* tightly packed plane: one copy */
+                            if (in) std::memcpy(cp, fp, (size_t)pw[p] * ph[p]);
+                            else std::memcpy(fp, cp, (size_t)pw[p] * ph[p]);
+                            continue;
                         }
+                        for (unsigned r = 0; r < ph[p]; r++) {
+                            if (in) std::memcpy(cp + (size_t)r * pw[p], fp + r * pitch, pw[p]);
+                            else std::memcpy(fp + r * pitch, cp + (size_t)r * pw[p], pw[p]);
+                        }
+                    }
             };
             unsigned prev_g0 = 0;
             size_t prev_k = 0;
