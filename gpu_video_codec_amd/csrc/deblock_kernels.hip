@@ -167,6 +167,7 @@ hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, h
 namespace {
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 /* cache-policy bits of the raw buffer builtins on gfx950: bit 1 = nt (streamed, evict first) */
 template <bool NT> constexpr int aux_bits() { return NT ? 2 : 0; }
@@ -298,6 +299,23 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         if (a.diag_prio & 1) __builtin_amdgcn_s_setprio(3);
     }
 #endif
+#ifdef HEVCDBK_DIAG
+    if constexpr (PATH == 0 && MODE == 1) {
+        if (a.diag_dummy & 32) {
+            /* copy diagnostic, knob dummy=32: the memory side of "lane pairs move 16 bytes" -- lanes 2k / 2k+1 load and store
+             * rows 0-3 / 4-7 of their two adjacent blocks as dwordx4 (no exchange: it is a copy); prices the access pattern
+             * a 16-byte-per-lane filter kernel would have, whose lane exchange would cost about 64 VALU instructions */
+            const uint32_t odd = (uint32_t)bx & 1u; /* interior waves start at an even bx: pairs (2k, 2k+1) */
+            const uint32_t voff = (uint32_t)((bx & ~1) * 8 - 4) + (odd ? 4u * (uint32_t)a.pitch : 0u);
+            u32x4 w[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (y0 + i) * (int)a.pitch, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) __builtin_amdgcn_raw_buffer_store_b128(w[i], rd, voff, (y0 + i) * (int)a.pitch, 0);
+            return;
+        }
+    }
+#endif
     if constexpr (PATH == 0) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -401,7 +419,6 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
     }
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 /*
  * 16-bit containers (bit depth 8..16), luma, scalar QP: same mapping, one lane = one offset block =

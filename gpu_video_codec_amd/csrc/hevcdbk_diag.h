@@ -37,7 +37,8 @@ extern "C" {
  *   prio=N    wave priority experiment: bit 0 = s_setprio 3 until the row loads are issued, bit 1 = from the final pack on
  *   dummy=N   N extra VALU instructions per wave (how the kernel time responds to VALU work); with the stripe map
  *             a bit set of timing experiments instead: 1 no bS DMA, 2 no stores, 4 no tile DMA, 8 no border,
- *             16 a workgroup barrier before the stores
+ *             16 a workgroup barrier before the stores; with the plain maps' copy variant: 32 = lane pairs move their
+ *             two blocks as dwordx4 rows (the access pattern of a 16-byte-per-lane kernel)
  *   nostrong | nonormal | barriers   luma ablations -- WRONG PIXELS, timing only
  * returns HEVCDBK_OK or HEVCDBK_ERR_ARG (unknown knob; nothing changed) */
 HEVCDBK_API int hevcdbk_diag_set(const char *spec);
