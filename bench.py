@@ -330,7 +330,7 @@ def main():
     ap.add_argument("--variant", choices=["auto", "generic", "packed", "copy"], default="auto",
                     help="copy = diagnostic memory-path ablation (dst = src, no filter), runs on libhevcdbk_diag.so; "
                          "never a benchmark result")
-    ap.add_argument("--map", choices=["auto", "rows", "linear", "tiles", "stripe"], default="auto",
+    ap.add_argument("--map", choices=["auto", "rows", "linear", "tiles", "stripe", "pipe", "group"], default="auto",
                     help="block -> lane map of the packed kernels (HEVCDBK_MAP_*; same bytes either way; stripe / tiles = the "
                          "experimental persistent-wave and LDS-tile maps of libhevcdbk_diag.so, never a result)")
     ap.add_argument("--diag", default=None,
@@ -372,13 +372,13 @@ def main():
             traffic = live_traffic(w, h, F, bd)   # BEFORE the first HIP call of this process
         if traffic is None and args.traffic in ("live", "file"):
             traffic = measured_traffic(w, h, F, bd)
-    if args.map in ("stripe", "tiles") and args.diag is None:
+    if args.map in ("stripe", "tiles", "pipe", "group") and args.diag is None:
         args.diag = ""   # the stripe and tile maps live in the diagnostic library only
     if args.variant == "copy" or args.diag is not None:
         _lib.use_diagnostic_library(args.diag)
     variant = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "packed": _lib.KERNEL_PACKED,
                "copy": _lib.DIAG_KERNEL_COPY}[args.variant]
-    variant |= {"auto": _lib.MAP_AUTO, "rows": _lib.MAP_ROWS, "linear": _lib.MAP_LINEAR, "tiles": _lib.DIAG_MAP_TILES, "stripe": _lib.DIAG_MAP_STRIPE}[args.map]
+    variant |= {"auto": _lib.MAP_AUTO, "rows": _lib.MAP_ROWS, "linear": _lib.MAP_LINEAR, "tiles": _lib.DIAG_MAP_TILES, "stripe": _lib.DIAG_MAP_STRIPE, "pipe": _lib.DIAG_MAP_PIPE, "group": _lib.DIAG_MAP_GROUP}[args.map]
     sb = 1 if bd == 8 else 2
     ndev = deblock.device_count()
     if ndev <= 0:

@@ -18,6 +18,8 @@ MAP_AUTO, MAP_ROWS, MAP_LINEAR = 0x000, 0x100, 0x200   # OR-ed into the kernel s
 DIAG_KERNEL_COPY = 100
 DIAG_MAP_STRIPE = 0x300
 DIAG_MAP_TILES = 0x400
+DIAG_MAP_PIPE = 0x500
+DIAG_MAP_GROUP = 0x600
 DIAG_LIB_PATH = os.path.join(_HERE, "libhevcdbk_diag.so")
 
 # every symbol include/hevc_deblock.h declares (tests check the library exports all of them)

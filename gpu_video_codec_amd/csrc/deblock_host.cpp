@@ -198,13 +198,13 @@ int launch(hevcdbk_context *ctx, const DbkArgs &a0, int sample_bytes, bool chrom
     const int map = variant & HEVCDBK_MAP_MASK;
     variant &= ~HEVCDBK_MAP_MASK;
     #ifdef HEVCDBK_DIAG
-    if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR && map != HEVCDBK_DIAG_MAP_TILES && map != HEVCDBK_DIAG_MAP_STRIPE) return HEVCDBK_ERR_ARG;
+    if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR && map != HEVCDBK_DIAG_MAP_TILES && map != HEVCDBK_DIAG_MAP_STRIPE && map != HEVCDBK_DIAG_MAP_PIPE && map != HEVCDBK_DIAG_MAP_GROUP) return HEVCDBK_ERR_ARG;
 #else
     if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR) return HEVCDBK_ERR_ARG;
 #endif
     DbkArgs a = a0;
     a.n_cus = ctx->n_cus;
-    a.map_override = map == HEVCDBK_MAP_ROWS ? 1 : (map == HEVCDBK_MAP_LINEAR ? 2 : (map == 0x300 ? 3 : (map == 0x400 ? 4 : 0)));
+    a.map_override = map == HEVCDBK_MAP_ROWS ? 1 : (map == HEVCDBK_MAP_LINEAR ? 2 : (map == 0x300 ? 3 : (map == 0x400 ? 4 : (map == 0x500 ? 5 : (map == 0x600 ? 6 : 0)))));
 #ifdef HEVCDBK_DIAG
     if (variant == HEVCDBK_DIAG_KERNEL_COPY) {
         if (!dbk_packed_supports(a, sample_bytes, chroma)) return HEVCDBK_ERR_UNSUPPORTED;
@@ -229,7 +229,7 @@ int launch(hevcdbk_context *ctx, const DbkArgs &a0, int sample_bytes, bool chrom
 /* hevcdbk_diag.h: the knobs of the diagnostic library (never compiled into libhevcdbk.so) */
 extern "C" HEVCDBK_API int hevcdbk_diag_set(const char *spec)
 {
-    DbkDiag d = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    DbkDiag d = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const std::string sp = spec ? spec : "";
     size_t i = 0;
     while (i < sp.size()) {
@@ -249,6 +249,7 @@ extern "C" HEVCDBK_API int hevcdbk_diag_set(const char *spec)
         else if (tok == "mode3") d.mode3 = 1;
         else if (tok.compare(0, 5, "prio=") == 0) d.prio = std::atoi(tok.c_str() + 5) & 3;
         else if (tok.compare(0, 6, "dummy=") == 0) d.dummy = std::atoi(tok.c_str() + 6);
+        else if (tok.compare(0, 5, "rows=") == 0) d.rows = std::atoi(tok.c_str() + 5);
         else if (tok.compare(0, 3, "wg=") == 0) {
             const int c = std::atoi(tok.c_str() + 3) / 64 * 64;
             if (c < 64 || c > 1024) return HEVCDBK_ERR_ARG;

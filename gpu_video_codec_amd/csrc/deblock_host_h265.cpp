@@ -61,12 +61,12 @@ int launch_h265(hevcdbk_context *ctx, const DbkH265Args &h0, int sample_bytes, b
     const int map = variant & HEVCDBK_MAP_MASK; /* as in dbkh::launch */
     variant &= ~HEVCDBK_MAP_MASK;
     #ifdef HEVCDBK_DIAG
-    if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR && map != HEVCDBK_DIAG_MAP_TILES && map != HEVCDBK_DIAG_MAP_STRIPE) return HEVCDBK_ERR_ARG;
+    if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR && map != HEVCDBK_DIAG_MAP_TILES && map != HEVCDBK_DIAG_MAP_STRIPE && map != HEVCDBK_DIAG_MAP_PIPE && map != HEVCDBK_DIAG_MAP_GROUP) return HEVCDBK_ERR_ARG;
 #else
     if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR) return HEVCDBK_ERR_ARG;
 #endif
     DbkH265Args h = h0;
-    h.base.map_override = map == HEVCDBK_MAP_ROWS ? 1 : (map == HEVCDBK_MAP_LINEAR ? 2 : (map == 0x300 ? 3 : (map == 0x400 ? 4 : 0)));
+    h.base.map_override = map == HEVCDBK_MAP_ROWS ? 1 : (map == HEVCDBK_MAP_LINEAR ? 2 : (map == 0x300 ? 3 : (map == 0x400 ? 4 : (map == 0x500 ? 5 : (map == 0x600 ? 6 : 0)))));
     const bool can_pack = dbk_packed_h265_supports(h, sample_bytes, chroma);
     hipError_t e;
     if (variant == HEVCDBK_KERNEL_PACKED) {

@@ -96,6 +96,7 @@ struct DbkDiag {
     int prio;      /* wave priority experiment, see DbkArgs::diag_prio */
     int dummy;     /* extra VALU instructions per wave */
     int mode3;     /* run the instrumented (MODE 3) instantiation even with no ablation set: the A/B baseline */
+    int rows;      /* pipe map: block rows per workgroup (default 4) */
 };
 extern DbkDiag g_dbk_diag;
 #endif

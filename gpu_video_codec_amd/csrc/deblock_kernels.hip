@@ -170,7 +170,14 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 /* cache-policy bits of the raw buffer builtins on gfx950: bit 1 = nt (streamed, evict first) */
-template <bool NT> constexpr int aux_bits() { return NT ? 2 : 0; }
+#ifndef DBK_AUX_LD /* experiment builds only (tools/exp): cache-policy bits of the pixel loads / stores */
+#define DBK_AUX_LD 0
+#endif
+#ifndef DBK_AUX_ST
+#define DBK_AUX_ST 0
+#endif
+template <bool NT> constexpr int aux_ld() { return NT ? 2 : DBK_AUX_LD; }
+template <bool NT> constexpr int aux_st() { return NT ? 2 : DBK_AUX_ST; }
 constexpr uint32_t kOob = 0xfffffff0u; /* voffset >= num_records: load returns 0, store is dropped */
 
 /*
@@ -278,8 +285,17 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
      *         image row) and is stored by nobody (split store: full lanes 8 bytes, edge lanes 4).
      * PATH 2: first / last block row: per-lane 4-byte accesses, out-of-image rows and halves via
      *         out-of-range offsets. */
+#ifdef HEVCDBK_DIAG
+    /* copy variant, knob "align": every lane moves the naturally aligned 8 bytes 8*bx .. 8*bx+7 (the last block of a row has
+     * none), so no 128-byte line is shared between two waves: the seam-free ceiling of the row map (timing only) */
+    const bool shifted = MODE == 1 && a.diag_xshift != 0;
+    if (shifted) active = active && bx < a.nbx - 1;
+    const bool lv = shifted ? active : (active && bx > 0);
+    const bool rv = shifted ? active : (active && bx < a.nbx - 1);
+#else
     const bool lv = active && bx > 0;            /* cols 0..3 inside the image */
     const bool rv = active && bx < a.nbx - 1;    /* cols 4..7 inside the image */
+#endif
     const int y0 = by * 8 - 4;
 #ifdef HEVCDBK_DIAG
     const uint32_t xoff = (uint32_t)(bx * 8 - 4) + (MODE == 1 ? (uint32_t)a.diag_xshift : 0u);
@@ -319,7 +335,7 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
     if constexpr (PATH == 0) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
+            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff, (y0 + r) * (int)a.pitch, aux_ld<NT>());
             L[r] = w.x;
             R[r] = w.y;
         }
@@ -331,7 +347,7 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         const int y0s = by0 * 8 - 4; /* scalar */
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (y0s + r) * (int)a.pitch, aux_bits<NT>());
+            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (y0s + r) * (int)a.pitch, aux_ld<NT>());
             L[r] = lv ? w.x : 0u;
             R[r] = rv ? (lv ? w.y : w.x) : 0u;
         }
@@ -342,8 +358,8 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         for (int r = 0; r < 8; r++) {
             const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
             const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
-            L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
-            R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && rv) ? off + 4u : kOob, 0, aux_bits<NT>());
+            L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && lv) ? off : kOob, 0, aux_ld<NT>());
+            R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && rv) ? off + 4u : kOob, 0, aux_ld<NT>());
         }
     }
 
@@ -392,7 +408,7 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             u32x2 w;
             w.x = L[r];
             w.y = R[r];
-            __builtin_amdgcn_raw_buffer_store_b64(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_st<NT>());
         }
     } else if constexpr (PATH == 1) {
         const uint32_t voff = xoff + (uint32_t)((by - by0) * 8) * (uint32_t)a.pitch;
@@ -404,8 +420,8 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             u32x2 w;
             w.x = L[r];
             w.y = R[r];
-            __builtin_amdgcn_raw_buffer_store_b64(w, rd, vfull, (y0s + r) * (int)a.pitch, aux_bits<NT>());
-            __builtin_amdgcn_raw_buffer_store_b32(lv ? L[r] : R[r], rd, vhalf, (y0s + r) * (int)a.pitch, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(w, rd, vfull, (y0s + r) * (int)a.pitch, aux_st<NT>());
+            __builtin_amdgcn_raw_buffer_store_b32(lv ? L[r] : R[r], rd, vhalf, (y0s + r) * (int)a.pitch, aux_st<NT>());
         }
     } else {
         const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
@@ -413,8 +429,8 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         for (int r = 0; r < 8; r++) {
             const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
             const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
-            __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
-            __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, (yv && rv) ? off + 4u : kOob, 0, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, (yv && lv) ? off : kOob, 0, aux_st<NT>());
+            __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, (yv && rv) ? off + 4u : kOob, 0, aux_st<NT>());
         }
     }
 }
@@ -451,7 +467,7 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
     if constexpr (!EDGE) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff, (y0 + r) * (int)a.pitch, aux_ld<NT>());
             W[r][0] = w.x; W[r][1] = w.y; W[r][2] = w.z; W[r][3] = w.w;
         }
     } else {
@@ -460,8 +476,8 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
         for (int r = 0; r < 8; r++) {
             const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
             const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
-            const u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(rs, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
-            const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rs, (yv && rv) ? off + 8u : kOob, 0, aux_bits<NT>());
+            const u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(rs, (yv && lv) ? off : kOob, 0, aux_ld<NT>());
+            const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rs, (yv && rv) ? off + 8u : kOob, 0, aux_ld<NT>());
             W[r][0] = l.x; W[r][1] = l.y; W[r][2] = rr.x; W[r][3] = rr.y;
         }
     }
@@ -498,7 +514,7 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
         for (int r = 0; r < 8; r++) {
             u32x4 w;
             w.x = W[r][0]; w.y = W[r][1]; w.z = W[r][2]; w.w = W[r][3];
-            __builtin_amdgcn_raw_buffer_store_b128(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b128(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_st<NT>());
         }
     } else {
         const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
@@ -508,8 +524,8 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
             const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
             u32x2 l, rr;
             l.x = W[r][0]; l.y = W[r][1]; rr.x = W[r][2]; rr.y = W[r][3];
-            __builtin_amdgcn_raw_buffer_store_b64(l, rd, (yv && lv) ? off : kOob, 0, aux_bits<NT>());
-            __builtin_amdgcn_raw_buffer_store_b64(rr, rd, (yv && rv) ? off + 8u : kOob, 0, aux_bits<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(l, rd, (yv && lv) ? off : kOob, 0, aux_st<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(rr, rd, (yv && rv) ? off + 8u : kOob, 0, aux_st<NT>());
         }
     }
 }
@@ -709,7 +725,7 @@ bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
 }
 
 #ifdef HEVCDBK_DIAG
-DbkDiag g_dbk_diag = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+DbkDiag g_dbk_diag = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static int wg_cap() { return g_dbk_diag.wg_cap; }
 #else
 /* workgroup width cap of the packed kernels (measured best on MI355X; the diagnostic build can vary it) */
@@ -932,6 +948,41 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
             return hipGetLastError();
         }
         b = b0;
+    }
+#endif
+#ifdef HEVCDBK_DIAG
+    if (a.map_override == 5 && sample_bytes == 1 && !chroma && !a.qp_map && a.by_count == 0 && a.max_v == 255) { /* HEVCDBK_DIAG_MAP_PIPE */
+        const int cap = wg_cap();
+        const int per_wg = a.nbx < cap ? a.nbx : cap;
+        const int n = g_dbk_diag.rows > 0 ? g_dbk_diag.rows : 4;
+        const dim3 block((per_wg + 63) / 64 * 64, 1, 1);
+        const dim3 grid((a.nby + n - 1) / n, a.n_frames, (a.nbx + (int)block.x - 1) / (int)block.x);
+        if (mode == 1) DBK_LAUNCH((dbk_pipe_kernel<1>), grid, block, stream, b, n);
+        else DBK_LAUNCH((dbk_pipe_kernel<0>), grid, block, stream, b, n);
+        return hipGetLastError();
+    }
+#endif
+#ifdef HEVCDBK_DIAG
+    if (a.map_override == 6 && sample_bytes == 1 && !chroma && !a.qp_map && a.by_count == 0 && a.max_v == 255 && a.nbx >= 3 && a.nby >= 3) { /* HEVCDBK_DIAG_MAP_GROUP */
+        const long long M = a.nbx - 1, rows = a.nby - 2;
+        int k = 1;
+        double best = 2.0;
+        for (int c = 1; c <= 8 && c <= rows; c++) {
+            const long long waves = (c * M + 63) / 64;
+            if (waves > 16) break;
+            const double waste = (double)(waves * 64 - c * M) / (double)(waves * 64);
+            if (waste + 1e-9 < best) { best = waste; k = c; }
+        }
+        const long long Wv = (k * M + 63) / 64, groups = (rows + k - 1) / k;
+        if (Wv <= 16 && (Wv * 64 + 64) * M < (1ll << 32)) {
+            const long long bwaves = (2ll * a.nbx + a.nby - 2 + 63) / 64, bwgs = (bwaves + Wv - 1) / Wv;
+            b.st_M = (int)M; b.st_k = k; b.st_W = (int)Wv; b.st_groups = (int)groups; b.st_border_wgs = (int)bwgs;
+            b.st_magic_M = M <= 1 ? 0u : (uint32_t)((1ull << 32) / (unsigned long long)M + 1ull);
+            const dim3 grid((unsigned)(bwgs + groups), (unsigned)a.n_frames, 1), block((unsigned)(64 * Wv), 1, 1);
+            if (mode == 1) DBK_LAUNCH((dbk_group_kernel<1>), grid, block, stream, b);
+            else DBK_LAUNCH((dbk_group_kernel<0>), grid, block, stream, b);
+            return hipGetLastError();
+        }
     }
 #endif
 #ifdef HEVCDBK_DIAG

@@ -25,6 +25,12 @@ extern "C" {
  * stores out, blocks filtered out of LDS between two barriers, column bx = 0 by a second tiny launch); 8-bit luma, scalar
  * QP, width a multiple of 128.  Bit-exact; measured SLOWER than the plain maps. */
 #define HEVCDBK_DIAG_MAP_TILES 0x400
+/* likewise: the row map with N block rows per workgroup (knob rows=N), a wave walking down its 64 columns with the next
+ * row's tile prefetched in registers while the current one is filtered */
+#define HEVCDBK_DIAG_MAP_PIPE 0x500
+/* likewise: k whole block rows (minus the column bx = 0) per workgroup, row-major inside the group so that no lane idles,
+ * plain one-shot waves; the frame border by extra workgroups of the same launch */
+#define HEVCDBK_DIAG_MAP_GROUP 0x600
 
 /* comma-separated knobs, process-wide, replacing the previous set (NULL or "" = defaults):
  *   wg=N      workgroup width cap of the packed kernels (64..1024, default 512)
@@ -39,6 +45,7 @@ extern "C" {
  *             a bit set of timing experiments instead: 1 no bS DMA, 2 no stores, 4 no tile DMA, 8 no border,
  *             16 a workgroup barrier before the stores; with the plain maps' copy variant: 32 = lane pairs move their
  *             two blocks as dwordx4 rows (the access pattern of a 16-byte-per-lane kernel)
+ *   rows=N    pipe map: block rows per workgroup (default 4)
  *   nostrong | nonormal | barriers   luma ablations -- WRONG PIXELS, timing only
  * returns HEVCDBK_OK or HEVCDBK_ERR_ARG (unknown knob; nothing changed) */
 HEVCDBK_API int hevcdbk_diag_set(const char *spec);

@@ -463,7 +463,11 @@ with deblock.Context(0) as ctx:
     # per group 1..8, a last group that is not full, fewer items than persistent workgroups and many more, in place,
     # per-frame random bS (every guard), a QP with tc = 0; operands it does not take fall back to the geometry's own map
     rng = np.random.default_rng(4242)
-    for variant in (_lib.KERNEL_PACKED | _lib.DIAG_MAP_STRIPE, _lib.KERNEL_PACKED | _lib.DIAG_MAP_TILES):
+    for variant in (_lib.KERNEL_PACKED | _lib.DIAG_MAP_STRIPE, _lib.KERNEL_PACKED | _lib.DIAG_MAP_TILES,
+                    _lib.KERNEL_PACKED | _lib.DIAG_MAP_PIPE, _lib.KERNEL_PACKED | _lib.DIAG_MAP_GROUP):
+        # ... the pipe map (HEVCDBK_DIAG_MAP_PIPE): N block rows per workgroup (knob rows=N, default 4), the next row's tile
+        # prefetched in registers; and the group map (HEVCDBK_DIAG_MAP_GROUP): k whole block rows minus column 0 per
+        # workgroup, no idle lanes, frame border by extra workgroups of the same launch
         # ... and the tile map (HEVCDBK_DIAG_MAP_TILES): whole block rows staged in LDS, blocks filtered out of LDS, column
         # bx = 0 by the second launch; 1..8 block rows per workgroup, a last workgroup that is not full, one-block-row heights
         for (w, h, n) in [(3840, 72, 2), (3840, 136, 3), (1920, 264, 2), (1280, 72, 5), (512, 40, 3), (128, 8, 2), (128, 24, 2),
@@ -507,6 +511,13 @@ def test_diagnostic_library_variants_are_bit_exact():
 def test_stripe_map_barrier_variant():
     """The stripe map once more with its "workgroup barrier before the stores" experiment switched on (knob dummy=16)."""
     _run_diag_child("dummy=16")
+
+
+def test_pipe_map_row_counts_and_barrier():
+    """The pipe map with other row counts per workgroup (3: a last group that is not full; 16: more rows than small planes
+    have) and with its "waves of a block row store together" barrier (knob dummy=64)."""
+    _run_diag_child("rows=3,dummy=64")
+    _run_diag_child("rows=16")
 
 
 def test_product_library_has_no_diagnostics(ctx):

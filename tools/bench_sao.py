@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--types", default="mix", help="mix (one third off / band / edge), off, band, edge: the SAO type of every CTB")
     a = ap.parse_args()
     w, h, n, bd = a.width, a.height, a.frames, a.bit_depth
     sb = 1 if bd == 8 else 2
@@ -25,6 +26,8 @@ def main():
     rows, cols = (h + 63) // 64, (w + 63) // 64
     prm = np.zeros((rows, cols), np.dtype(_lib.SAO_CTB_DTYPE))
     prm["type"] = rng.randint(0, 3, (rows, cols))
+    if a.types != "mix":
+        prm["type"] = {"off": 0, "band": 1, "edge": 2}[a.types]
     prm["cls"] = np.where(prm["type"] == 1, rng.randint(0, 32, (rows, cols)), rng.randint(0, 4, (rows, cols)))
     prm["offset"] = rng.randint(-7, 8, (rows, cols, 4))
     dp = ctx.alloc(prm.nbytes)
@@ -40,7 +43,7 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     nbytes = 2 * n * w * h * sb
     print(json.dumps({"stage": "sao", "ms_per_launch": dt * 1e3, "frames_per_s": n / dt, "GBps": nbytes / dt * 1e-9,
-                      "frac_of_8TBps": nbytes / dt / 8e12, "workload": "%dx%d %d-bit luma x %d" % (w, h, bd, n)}))
+                      "frac_of_8TBps": nbytes / dt / 8e12, "workload": "%dx%d %d-bit luma x %d, CTB types: %s" % (w, h, bd, n, a.types)}))
 
 
 if __name__ == "__main__":
