@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--traffic", choices=["live", "file", "none"], default="live",
                     help="roofline.traffic: live = PMC passes (rocprofv3) run as child processes before this process touches "
                          "the GPU (about 20 s); file = newest matching profiles/*_hbm_traffic.json; live falls back to file")
+    ap.add_argument("--no-telemetry", action="store_true", help="do not sample the card's clock / power files during the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and the reference table line")
@@ -399,10 +400,20 @@ def main():
     if args.warmup > 0:
         ctx.run_timed([planes], args.qp, args.warmup, variant=variant)
     barrier()
+    sampler = None
+    if not args.no_telemetry:
+        try:  # engine clock and socket power of THIS rank's card during the timed region (amdgpu sysfs; None where unreadable)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from clock_power_trace import Sampler
+            sampler = Sampler(local_rank % ndev).start()
+        except Exception:
+            sampler = None
     t0 = time.perf_counter()
     kernel_ms = ctx.run_timed([planes], args.qp, args.steps, variant=variant)  # K launches, one sync at the end
     ctx.synchronize()
-    elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    telemetry = sampler.stop(t0 + 0.2 * elapsed, t1) if sampler is not None else None
     barrier()
     elapsed = shard.max_over_ranks(dist, elapsed)  # MAX over ranks (gloo; control plane only)
 
@@ -420,6 +431,12 @@ def main():
     roof["traffic"] = traffic[0] if traffic else None
     roof["traffic_source"] = traffic[1] if traffic else None
     roof["read_GBps"] = (abytes - w * h * sb * F) / (roof["kernel_avg_ms"] * 1e-3) / 1e9
+    if telemetry and telemetry.get("samples"):
+        # the filter runs into the socket power cap: the engine clock it gets is part of what bounds it
+        roof["engine_clock_MHz"] = telemetry["engine_clock_MHz"]
+        roof["socket_power_W"] = telemetry["socket_power_W"]
+        roof["power_cap_W"] = telemetry["power_cap_W"]
+        roof["telemetry_samples"] = telemetry["samples"]
     out = {
         "metric": "luma_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,

@@ -380,7 +380,17 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
 #else
         dbk::packed_filter_block<CHROMA>(L, R, bs, q);
 #endif
-    } else if constexpr (MODE == 2) { /* spec-exact mode, H.265 8.7.2 */
+    }
+#ifdef HEVCDBK_DIAG
+    else if constexpr (MODE == 1) {
+        /* copy variant, knob dummy=128: the four bS byte loads of the filter ride along (what they cost the memory path) */
+        if (a.diag_dummy & 128) {
+            const dbk::BlockBs bs = load_bs_buffer<PATH != 0>(a, f, by, bx, active);
+            if (bs.ver1 + bs.ver2 + bs.hor1 + bs.hor2 == 0x7fffffff) L[0] ^= 1u; /* never true: keeps the loads alive */
+        }
+    }
+#endif
+    else if constexpr (MODE == 2) { /* spec-exact mode, H.265 8.7.2 */
         int entry[4];
         load_bs_buffer_h265<PATH>(a, f, by, bx, active, entry);
         dbk::H265Seg sg;
