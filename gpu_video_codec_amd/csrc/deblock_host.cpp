@@ -319,7 +319,7 @@ int launch_frame_fused(hevcdbk_context *ctx, const DbkArgs *args, int npl, unsig
     const int sbs[3] = {(int)sb, (int)sb, (int)sb};
     *done = false;
     if (!dbk_multi_supports(args, npl, sbs)) return HEVCDBK_OK;
-    if (!hip_ok(ctx, dbk_launch_packed_multi(args, npl, s), "kernel launch")) return HEVCDBK_ERR_HIP;
+    if (!hip_ok(ctx, dbk_launch_packed_multi(args, npl, (int)sb, s), "kernel launch")) return HEVCDBK_ERR_HIP;
     *done = true;
     return HEVCDBK_OK;
 }
@@ -542,7 +542,7 @@ static int launch_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *plan
             ok = ok && (i == 0 || planes[i].is_chroma) && dbk_packed_supports(args[i], sbs[i], planes[i].is_chroma != 0);
         }
         if (ok && dbk_multi_supports(args, (int)n_planes, sbs))
-            return hip_ok(ctx, dbk_launch_packed_multi(args, (int)n_planes, s), "kernel launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+            return hip_ok(ctx, dbk_launch_packed_multi(args, (int)n_planes, sbs[0], s), "kernel launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
     }
     for (unsigned i = 0; i < n_planes; i++)
         if (int rc = launch(ctx, args[i], (int)planes[i].sample_bytes, planes[i].is_chroma != 0, kernel_variant, s)) return rc;
@@ -691,7 +691,7 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
         /* planes that are page-locked caller memory themselves (and word aligned) need no staging either */
         bool direct = true;
         for (int i = 0; i < npl && direct; i++)
-            direct = frame->pitch[i] % 4 == 0 && (uintptr_t)frame->plane[i] % 4 == 0 && is_pinned_host(frame->plane[i]);
+            direct = frame->pitch[i] % (4 * sb) == 0 && (uintptr_t)frame->plane[i] % (4 * sb) == 0 && is_pinned_host(frame->plane[i]);
         if (!direct)
             for (int i = 0; i < npl; i++) {
                 const size_t rb = (size_t)pw[i] * sb;
@@ -709,6 +709,9 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
         HIP_TRY(ctx, hipEventRecord(ev[4], ctx->compute));
         bool fused = false;
         if (int rc = launch_frame_fused(ctx, ha, npl, sb, ctx->compute, &fused)) return rc;
+        if (!fused) /* operands the fused launch does not take after all (alignment of the caller's planes): plane by plane */
+            for (int k = 0; k < npl; k++)
+                if (int rc = launch(ctx, ha[k], (int)sb, k != 0, HEVCDBK_KERNEL_AUTO, ctx->compute)) return rc;
         HIP_TRY(ctx, hipEventRecord(ev[5], ctx->compute));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
         if (!direct)
@@ -740,6 +743,9 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
         HIP_TRY(ctx, hipEventRecord(ev[4], ctx->compute));
         bool fused = false;
         if (int rc = launch_frame_fused(ctx, args, npl, sb, ctx->compute, &fused)) return rc;
+        if (!fused)
+            for (int k = 0; k < npl; k++)
+                if (int rc = launch(ctx, args[k], (int)sb, k != 0, HEVCDBK_KERNEL_AUTO, ctx->compute)) return rc;
         HIP_TRY(ctx, hipEventRecord(ev[5], ctx->compute));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->pin[0].p, ctx->dev[0].p, frame_bytes, hipMemcpyDeviceToHost, ctx->compute));
         HIP_TRY(ctx, hipEventRecord(ev[9], ctx->compute));

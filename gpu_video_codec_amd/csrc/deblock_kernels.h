@@ -74,13 +74,14 @@ hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, h
 hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, int mode, hipStream_t stream);
 bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma);
 
-/* the planes of one 4:2:0 frame (or batch of frames) in one launch: 8-bit, scalar QP, plane 0 = luma */
+/* the planes of one 4:2:0 frame (or batch of frames) in one launch: all 8-bit or all 16-bit containers (<= 12 bit), scalar QP,
+ * plane 0 = luma */
 struct DbkMultiArgs {
     DbkArgs p[3];
     int row_end[3]; /* cumulative block-row counts: blockIdx.x < row_end[i] belongs to plane <= i */
 };
 bool dbk_multi_supports(const DbkArgs *planes, int n, const int *sample_bytes);
-hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t stream);
+hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, int sample_bytes, hipStream_t stream);
 
 #ifdef HEVCDBK_DIAG
 /* knobs of the diagnostic build, set through hevcdbk_diag_set() (hevcdbk_diag.h); the product library has none of this and

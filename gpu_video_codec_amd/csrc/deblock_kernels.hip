@@ -702,6 +702,28 @@ __global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiAr
 }
 
 
+/* the same for 16-bit containers (bit depth 8..12; WIDE = 12-bit luma, deblock_packed.h): Y, U, V of a 10-bit 4:2:0 batch in
+ * one launch */
+template <bool WIDE>
+__global__ __launch_bounds__(1024) void dbk_packed16_multi_kernel(const DbkMultiArgs m)
+{
+    const int row = blockIdx.x;
+    const int pl = row >= m.row_end[0] ? (row >= m.row_end[1] ? 2 : 1) : 0; /* scalar */
+    const DbkArgs &a = m.p[pl];
+    const int by = row - (pl ? m.row_end[pl - 1] : 0), f = blockIdx.y;
+    const int bx = blockIdx.z * (int)blockDim.x + (int)threadIdx.x;
+    const int wave_bx0 = __builtin_amdgcn_readfirstlane(bx) & ~63;
+    if (wave_bx0 >= a.nbx) return; /* chroma rows are narrower than the workgroup */
+    const bool active = bx < a.nbx;
+    const bool interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && by > 0 && by < a.nby - 1;
+    if (pl == 0) {
+        if (interior) packed16_body<0, false, false, false, false, WIDE>(a, by, f, bx, true);
+        else packed16_body<0, false, true, false, false, WIDE>(a, by, f, bx, active);
+    } else {
+        if (interior) packed16_body<0, false, false, false, true>(a, by, f, bx, true);
+        else packed16_body<0, false, true, false, true>(a, by, f, bx, active);
+    }
+}
 
 #ifdef HEVCDBK_DIAG
 /* the measured-and-rejected kernels (LDS queue, stripe map, tile map): diagnostic build only, DESIGN.md 4.1 */
@@ -1020,7 +1042,8 @@ hipError_t dbk_launch_packed(const DbkArgs &a, int sample_bytes, bool chroma, in
     return hipGetLastError();
 }
 
-/* all planes 8-bit, scalar QP, same frame count; plane 0 luma, the others chroma */
+/* all planes of one sample width and bit depth that the packed kernels take (8-bit, or 16-bit containers up to 12 bit),
+ * scalar QP, same frame count; plane 0 luma, the others chroma */
 bool dbk_multi_supports(const DbkArgs *planes, int n, const int *sample_bytes)
 {
 #ifdef HEVCDBK_DIAG
@@ -1028,13 +1051,14 @@ bool dbk_multi_supports(const DbkArgs *planes, int n, const int *sample_bytes)
 #endif
     if (n < 2 || n > 3) return false;
     for (int i = 0; i < n; i++)
-        if (sample_bytes[i] != 1 || planes[i].qp_map || planes[i].max_v != 255 || planes[i].n_frames != planes[0].n_frames ||
-            planes[i].nbx > planes[0].nbx)
+        if (sample_bytes[i] != sample_bytes[0] || planes[i].qp_map || planes[i].max_v != planes[0].max_v ||
+            planes[i].n_frames != planes[0].n_frames || planes[i].nbx > planes[0].nbx ||
+            !dbk_packed_supports(planes[i], sample_bytes[i], i > 0))
             return false;
     return planes[0].nbx <= 1024;
 }
 
-hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t stream)
+hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, int sample_bytes, hipStream_t stream)
 {
     DbkMultiArgs m;
     std::memset(&m, 0, sizeof(m));
@@ -1051,7 +1075,9 @@ hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, hipStream_t str
     const int per_wg = planes[0].nbx < cap ? planes[0].nbx : cap;
     dim3 block((per_wg + 63) / 64 * 64, 1, 1);
     dim3 grid(rows, planes[0].n_frames, (planes[0].nbx + (int)block.x - 1) / (int)block.x);
-    DBK_LAUNCH((dbk_packed_multi_kernel<false>), grid, block, stream, m);
+    if (sample_bytes == 1) DBK_LAUNCH((dbk_packed_multi_kernel<false>), grid, block, stream, m);
+    else if (planes[0].max_v > 2047) DBK_LAUNCH((dbk_packed16_multi_kernel<true>), grid, block, stream, m);
+    else DBK_LAUNCH((dbk_packed16_multi_kernel<false>), grid, block, stream, m);
     return hipGetLastError();
 }
 

@@ -191,9 +191,10 @@ HEVCDBK_API int hevc_deblocking_filter_device(hevcdbk_context *ctx, const hevcdb
                                   void *hip_stream /* NULL => the context's compute stream */);
 
 /* The planes of a batch of frames in ONE call -- normally Y, U, V of a 4:2:0 batch (planes[0] luma; 1 <= n_planes <= 3; all
- * with the same n_frames).  Replaces the reference's three launches per frame (gpu.cu:1266-1285): when every plane is 8 bit
- * with a scalar QP (the reference's case) they go out as ONE fused launch, whatever the frame size; other operands are
- * launched plane by plane, exactly as n_planes calls of hevc_deblocking_filter_device would.  Same bytes either way. */
+ * with the same n_frames).  Replaces the reference's three launches per frame (gpu.cu:1266-1285): when the planes share one
+ * sample format that the packed kernels take (8 bit -- the reference's case -- or 16-bit containers up to 12 bit) and a scalar
+ * QP they go out as ONE fused launch, whatever the frame size; other operands (a QP map, deeper samples) are launched plane by
+ * plane, exactly as n_planes calls of hevc_deblocking_filter_device would.  Same bytes either way. */
 HEVCDBK_API int hevc_deblocking_filter_device_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *planes,
                                          unsigned n_planes, unsigned qp, const hevcdbk_tables *tables,
                                          int kernel_variant, void *hip_stream);

@@ -391,11 +391,13 @@ def test_row_major_mapping_forced(ctx, oracle):
 
 
 def test_device_planes_one_call_large_frames(ctx, oracle):
-    """hevc_deblocking_filter_device_planes: Y, U, V of a batch of LARGE 4:2:0 frames in one call (one fused launch for 8-bit
-    scalar-QP planes, SURVEY 8f rank 1, no frame-size gate), and the operands the fused kernel does not take (10 bit, a QP
-    map) through the same entry, plane by plane: same bytes as the oracle plane by plane."""
+    """hevc_deblocking_filter_device_planes: Y, U, V of a batch of LARGE 4:2:0 frames in one call (one fused launch for
+    scalar-QP planes of one bit depth, 8-bit or 16-bit containers up to 12 bit, SURVEY 8f rank 1, no frame-size gate), and the
+    operands the fused kernels do not take (a QP map) through the same entry, plane by plane: same bytes as the oracle plane by
+    plane.  10 / 11 bit = the plain 16-bit core, 12 bit = its WIDE luma variant; rows narrower and wider than a workgroup."""
     from gpu_video_codec_amd import deblock, synth, _lib
-    for (w, h, n, bd) in [(3840, 144, 2, 8), (1920, 1088, 2, 8), (7680, 48, 1, 8), (1280, 80, 3, 10)]:
+    for (w, h, n, bd) in [(3840, 144, 2, 8), (1920, 1088, 2, 8), (7680, 48, 1, 8), (1280, 80, 3, 10), (3840, 144, 2, 10),
+                          (16, 16, 2, 10), (8208, 32, 1, 11), (1936, 80, 2, 12)]:
         ys = np.stack([synth.blocky_plane(w, h, seed=10 + f, bit_depth=bd) for f in range(n)])
         us = np.stack([synth.blocky_plane(w // 2, h // 2, seed=20 + f, bit_depth=bd, dc_range=4) for f in range(n)])
         vs = np.stack([synth.blocky_plane(w // 2, h // 2, seed=30 + f, bit_depth=bd, dc_range=4) for f in range(n)])
@@ -639,6 +641,50 @@ def test_fused_launch_and_resident_default_bs(ctx, oracle):
     for i, pl in enumerate(frames):
         assert oracle.join_yuv420(*pl) == want[i], i
     run(352, 288, 10, 35, False)
+
+
+def test_host_frame_operator_16bit_containers(ctx, oracle):
+    """hevc_deblocking_filter on 10 / 12-bit 4:2:0 frames in 16-bit containers: small frames (one fused Y+U+V launch of the
+    16-bit kernels working on page-locked memory, no DMA), pitched caller planes whose rows are not 8-byte aligned (staged into
+    the tightly packed pinned buffer), page-locked caller planes (worked on where they lie), and a large frame (strip pipeline).  Parity
+    unpinned beyond 8 bit (the reference is 8-bit only): checked against the CPU restatement."""
+    from gpu_video_codec_amd import synth
+
+    def want_of(planes, qp, bd, **kw):
+        return [oracle.filter_plane(planes[0], qp, bit_depth=bd, vert_bs=kw.get("vert_bs"), hor_bs=kw.get("hor_bs")),
+                oracle.filter_plane(planes[1], qp, bit_depth=bd, is_chroma=True),
+                oracle.filter_plane(planes[2], qp, bit_depth=bd, is_chroma=True)]
+
+    for (w, h, bd, qp, seed) in [(352, 288, 10, 35, 1), (16, 16, 10, 40, 2), (1040, 32, 12, 38, 3), (1280, 720, 10, 30, 4),
+                                 (3840, 2160, 10, 32, 5)]:
+        src = synth.blocky_yuv420(w, h, seed=seed, bit_depth=bd)
+        kw = {}
+        if seed == 1:
+            kw["vert_bs"], kw["hor_bs"] = oracle.lcg_bs(w, h, seed)
+        want = want_of(src, qp, bd, **kw)
+        got = [p.copy() for p in src]
+        ctx.filter_frame(*got, qp=qp, bit_depth=bd, **kw)
+        for g, x in zip(got, want):
+            assert np.array_equal(g, x), (w, h, bd)
+        if w <= 1280:
+            # pitched views: 3 samples of row padding = 6 bytes, rows not 8-byte aligned
+            bufs = [np.full((p.shape[0], p.shape[1] + 3), 0x0155, np.uint16) for p in src]
+            views = [b[:, :p.shape[1]] for b, p in zip(bufs, src)]
+            for vw, p in zip(views, src):
+                vw[:] = p
+            ctx.filter_frame(*views, qp=qp, bit_depth=bd, **kw)
+            assert all((b[:, -3:] == 0x0155).all() for b in bufs)
+            for vw, x in zip(views, want):
+                assert np.array_equal(vw, x), (w, h, bd, "pitched")
+            # page-locked caller planes: the kernel works on them where they lie
+            pinned = [ctx.pinned_array(p.shape, np.uint16) for p in src]
+            for pp, p in zip(pinned, src):
+                pp[:] = p
+            ctx.filter_frame(*pinned, qp=qp, bit_depth=bd, **kw)
+            for pp, x in zip(pinned, want):
+                assert np.array_equal(pp, x), (w, h, bd, "pinned")
+            for pp in pinned:
+                ctx.free_pinned(pp)
 
 
 def test_multi_frame_yuv_file_operator(ctx, oracle, golden_inputs, tmp_path):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Device-resident rate of whole 4:2:0 frames (Y + U + V, BASELINE config 4), reference-exact mode: three launches per step
-over batches of F frames, per-step HIP-event time.  Diagnostic beside bench.py (whose metric is luma frames/s)."""
+"""Device-resident rate of whole 4:2:0 frames (Y + U + V, BASELINE config 4), reference-exact mode: one fused launch per step (three with
+--diag nofuse) over batches of F frames, per-step HIP-event time.  Diagnostic beside bench.py (whose metric is luma frames/s)."""
 import argparse, json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,10 @@ def main():
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--diag", default=None, help="load libhevcdbk_diag.so with these knobs, e.g. nofuse (three launches per step)")
     a = ap.parse_args()
+    if a.diag is not None:
+        _lib.use_diagnostic_library(a.diag)
     w, h, F, bd = a.width, a.height, a.frames, a.bit_depth
     sb = 1 if bd == 8 else 2
     ctx = deblock.Context(0)
@@ -32,7 +35,7 @@ def main():
         ms = ctx.run_timed(planes, a.qp, a.steps, variant=variant)
         nbytes = F * sb * 2 * (w * h + 2 * (w // 2) * (h // 2))
         t = float(np.mean(ms)) * 1e-3
-        print(json.dumps({"workload": "%dx%d %d-bit 4:2:0 x %d frames, QP %d, default bS" % (w, h, bd, F, a.qp), "kernels": name,
+        print(json.dumps({"workload": "%dx%d %d-bit 4:2:0 x %d frames, QP %d, default bS" % (w, h, bd, F, a.qp), "kernels": name, "diag": a.diag,
                           "ms_per_step": t * 1e3, "yuv420_frames_per_s": F / t, "sample_GBps": nbytes / t * 1e-9,
                           "frac_of_8TBps": nbytes / t / 8e12}))
 
