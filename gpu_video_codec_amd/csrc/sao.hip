@@ -199,24 +199,27 @@ __device__ __forceinline__ SaoRow sao_load_row(const uint8_t *row, int x, int w)
 
 typedef short spk __attribute__((vector_size(4)));
 __device__ __forceinline__ spk s_pk(uint32_t v) { return __builtin_bit_cast(spk, v); }
-__device__ __forceinline__ uint32_t s_bits(spk v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ spk s_splat(int v) { return spk{(short)v, (short)v}; }
-__device__ __forceinline__ spk s_clamp(spk v, int lo, int hi)
-{
-    return __builtin_elementwise_min(__builtin_elementwise_max(v, s_splat(lo)), s_splat(hi));
-}
+typedef unsigned short supk __attribute__((vector_size(4)));
+__device__ __forceinline__ supk s_upk(uint32_t v) { return __builtin_bit_cast(supk, v); }
+/* max(a - b, 0) in both halves: ONE v_pk_sub_u16 with the clamp bit (unsigned saturation) */
+__device__ __forceinline__ supk s_sub_sat(supk a, supk b) { return __builtin_elementwise_sub_sat(a, b); }
 
-/* rec + offset[index], clipped to 8 bit: tab_lo / tab_hi hold the five offset bytes + 128 */
+/* rec + offset[index], clipped to 8 bit: tab_lo / tab_hi hold the five offset bytes + 128.  rec + t is non-negative, so
+ * the lower clip is the saturation of the unsigned subtraction of the bias */
 __device__ __forceinline__ uint32_t sao_apply(uint32_t rec, uint32_t idx, uint32_t tab_lo, uint32_t tab_hi)
 {
     const uint32_t t = __builtin_amdgcn_perm(tab_hi, tab_lo, idx | 0x0c000c00u);
-    return s_bits(s_clamp(s_pk(rec) + s_pk(t) - s_splat(128), 0, 255));
+    const supk v = s_sub_sat(s_upk(rec) + s_upk(t), supk{128, 128});
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, supk{255, 255}));
 }
-/* edge index of both samples of `rec` against the neighbour pairs a and b: 0..4, 2 = neither minimum nor maximum */
+/* edge index of both samples of `rec` against the neighbour pairs a and b: 0..4, 2 = neither minimum nor maximum;
+ * clamp(rec + 1 - a, 0, 2) = min(saturating (rec + 1) - a, 2) */
 __device__ __forceinline__ uint32_t sao_edge_idx(uint32_t rec, uint32_t a, uint32_t b)
 {
-    const spk r1 = s_pk(rec) + s_splat(1);
-    return s_bits(s_clamp(r1 - s_pk(a), 0, 2) + s_clamp(r1 - s_pk(b), 0, 2));
+    const supk r1 = s_upk(rec) + supk{1, 1}, two = supk{2, 2};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(s_sub_sat(r1, s_upk(a)), two) +
+                                            __builtin_elementwise_min(s_sub_sat(r1, s_upk(b)), two));
 }
 
 template <bool BORDER>

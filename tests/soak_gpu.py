@@ -2,7 +2,8 @@
 """Randomised soak of the HIP path against the oracles (run by hand on a GPU box; not collected by pytest):
    python tests/soak_gpu.py [--cases 400] [--seed 1]
 Every case draws a geometry, bit depth, plane kind, QP (scalar or map), bS arrays, frame count, in-place or not, and runs
-both kernels of the reference-exact mode and of the spec-exact mode; any mismatch prints the case and exits non-zero."""
+both kernels of the reference-exact mode and of the spec-exact mode, and every third case a whole 4:2:0 batch through
+hevc_deblocking_filter_device_planes and the host-frame operator; any mismatch prints the case and exits non-zero."""
 import argparse, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -94,6 +95,33 @@ def main():
                 if b.qp_map is not None:
                     b.qp_map.free()
                 b.free()
+        # every third case also as a whole 4:2:0 frame batch: Y, U, V in one call (the fused launch where it applies, 8-bit and
+        # 16-bit containers) and through the host-frame operator (small frames: no DMA; large: strips)
+        if case % 3 == 0 and w % 16 == 0 and h % 16 == 0:
+            n2 = int(rng.randint(1, 3))
+            yuv = [synth.blocky_yuv420(w, h, seed=int(rng.randint(1, 1 << 30)), bit_depth=bd) for _ in range(n2)]
+            want = [[oracle.filter_plane(fr[0], min(qp, 60), bit_depth=bd), oracle.filter_plane(fr[1], min(qp, 60), bit_depth=bd, is_chroma=True),
+                     oracle.filter_plane(fr[2], min(qp, 60), bit_depth=bd, is_chroma=True)] for fr in yuv]
+            bat = []
+            for i, ch in ((0, False), (1, True), (2, True)):
+                pl = np.stack([fr[i] for fr in yuv])
+                bb = deblock.DeviceBatch(ctx, pl.shape[2], pl.shape[1], n2, bit_depth=bd, is_chroma=ch, in_place=in_place)
+                bb.upload_all(pl)
+                bat.append(bb)
+            ctx.filter_device_planes([bb.planes() for bb in bat], qp)
+            ctx.synchronize()
+            for i, bb in enumerate(bat):
+                for f in range(n2):
+                    if not np.array_equal(bb.download_frame(f), want[f][i]):
+                        print("MISMATCH planes", i, f, tag)
+                        bad += 1
+                bb.free()
+            got = [p.copy() for p in yuv[0]]
+            ctx.filter_frame(*got, qp=min(qp, 60), bit_depth=bd)
+            for i in range(3):
+                if not np.array_equal(got[i], want[0][i]):
+                    print("MISMATCH host frame", i, tag)
+                    bad += 1
         if case % 50 == 49:
             print("soak: %d cases, %d mismatches" % (case + 1, bad), flush=True)
     print("soak done: %d cases, %d mismatches" % (a.cases, bad))
