@@ -757,7 +757,7 @@ bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
 }
 
 #ifdef HEVCDBK_DIAG
-DbkDiag g_dbk_diag = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+DbkDiag g_dbk_diag = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static int wg_cap() { return g_dbk_diag.wg_cap; }
 #else
 /* workgroup width cap of the packed kernels (measured best on MI355X; the diagnostic build can vary it) */
@@ -771,7 +771,11 @@ static void launch_packed_t(const DbkArgs &a, int sample_bytes, bool chroma, int
 #ifdef HEVCDBK_DIAG
     if (mode == 1) { /* copy: the kernel's loads and stores, no arithmetic */
         if (sample_bytes == 2) DBK_LAUNCH((dbk_packed16_kernel<1, NT, LINEAR, false>), grid, block, stream, a);
-        else DBK_LAUNCH((dbk_packed_kernel<false, 1, NT, LINEAR, false>), grid, block, stream, a);
+        else DBK_LAUNCH_LDS((dbk_packed_kernel<false, 1, NT, LINEAR, false>), grid, block, g_dbk_diag.lds, stream, a);
+        return;
+    }
+    if (g_dbk_diag.lds && sample_bytes == 1 && !chroma && !qm) { /* occupancy experiment: unused dynamic LDS per workgroup */
+        DBK_LAUNCH_LDS((dbk_packed_kernel<false, 0, NT, LINEAR, false>), grid, block, g_dbk_diag.lds, stream, a);
         return;
     }
     if (sample_bytes == 1 && !chroma && !qm && a.use_queue && block.x <= 512) {

@@ -46,6 +46,8 @@ extern "C" {
  *             16 a workgroup barrier before the stores; with the plain maps' copy variant: 32 = lane pairs move their
  *             two blocks as dwordx4 rows (the access pattern of a 16-byte-per-lane kernel)
  *   rows=N    pipe map: block rows per workgroup (default 4)
+ *   lds=N     N bytes of unused dynamic LDS per workgroup of the plain 8-bit luma kernel and its copy variant: limits the
+ *             workgroups per CU (160 KiB / N) for occupancy A/B runs
  *   nostrong | nonormal | barriers   luma ablations -- WRONG PIXELS, timing only
  * returns HEVCDBK_OK or HEVCDBK_ERR_ARG (unknown knob; nothing changed) */
 HEVCDBK_API int hevcdbk_diag_set(const char *spec);

@@ -52,6 +52,12 @@ python3 "$R/tools/sq_counters.py" --tag copy_4k8 --variant copy > "$OUT/sq_count
 cp "$R"/gpurun_out/sq/packed_4k8.json "$OUT/sq_counters_packed_4k8.json" 2>/dev/null || true
 cp "$R"/gpurun_out/sq/copy_4k8.json "$OUT/sq_counters_copy_4k8.json" 2>/dev/null || true
 python3 "$R/tools/clock_trace.py" 300 packed > "$OUT/clock_trace_packed_4k8.txt" 2>&1 || true
+# engine clock / socket power while the kernels run (amdgpu sysfs): the filter, its copy variant, the 8K 10-bit kernel
+python3 "$R/tools/clock_power_trace.py" > "$OUT/clock_power_filter_4k8.json" 2>/dev/null || true
+python3 "$R/tools/clock_power_trace.py" --variant copy > "$OUT/clock_power_copy_4k8.json" 2>/dev/null || true
+python3 "$R/tools/clock_power_trace.py" --width 7680 --height 4320 --bit-depth 10 --frames 32 > "$OUT/clock_power_8k10.json" 2>/dev/null || true
+python3 "$R/tools/bench_yuv420.py" --bit-depth 10 --frames 48 > "$OUT/bench_yuv420_10bit.json" 2>/dev/null || true
+python3 "$R/tools/bench_yuv420.py" --bit-depth 10 --frames 48 --diag nofuse > "$OUT/bench_yuv420_10bit_nofuse.json" 2>/dev/null || true
 "$R/tools/ubench/valu_rate" > "$OUT/ubench_valu_rate.txt" 2>&1 || true
 "$R/tools/ubench/copy_bw" > "$OUT/ubench_copy_bw.txt" 2>&1 || true
 rm -rf "$OUT"/bench_default_1gpu "$OUT"/bench_8k10_1gpu "$OUT"/bench_h265 "$OUT"/e2e_small "$OUT"/bench_sao "$OUT"/kernel_trace_bench_*.csv "$OUT"/kernel_trace_e2e_small.csv
