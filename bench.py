@@ -437,6 +437,8 @@ def main():
         roof["socket_power_W"] = telemetry["socket_power_W"]
         roof["power_cap_W"] = telemetry["power_cap_W"]
         roof["telemetry_samples"] = telemetry["samples"]
+        roof["telemetry_note"] = ("amdgpu sysfs of this rank's card over the last 80 % of the timed region; the power file is a slow "
+                                  "average and reads low in a region this short (tools/clock_power_trace.py holds the load for seconds)")
     out = {
         "metric": "luma_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
