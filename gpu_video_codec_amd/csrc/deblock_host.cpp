@@ -668,7 +668,7 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
     for (int i = 0; i < npl; i++)
         if (int rc = frame_plane_args(ctx, dplane, i, W, H, frame->bit_depth, sb, chroma, qp, dmap, tables, args[i])) return rc;
 
-    /* Small 8-bit 4:2:0 frames, where a DMA or a launch costs more than the work it carries: one H2D, one fused
+    /* Small 4:2:0 frames (8-bit or 16-bit containers), where a DMA or a launch costs more than the work it carries: one H2D, one fused
      * launch, one D2H, all on the compute stream (no cross-stream events to pay for). */
     const int sbs[3] = {(int)sb, (int)sb, (int)sb};
     const bool small = chroma && frame_bytes <= ((size_t)2 << 20) && dbk_multi_supports(args, npl, sbs);
