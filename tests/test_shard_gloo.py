@@ -168,3 +168,15 @@ def test_bench_gpus_flag_spawns_before_any_gpu_call(tmp_path, monkeypatch):
     r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr
     assert r.stdout.strip() == "NOTLOADED"
+
+
+def test_clock_power_sampler_without_a_card():
+    """bench.py wraps its timed region in tools/clock_power_trace.Sampler; with no readable amdgpu sysfs files (this
+    container, or a box that hides them) it must cost nothing and report nothing."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from clock_power_trace import Sampler, _current_mhz
+    s = Sampler(0, pci="ffff:ff:1f.7").start()   # a PCI address no card has: no HIP call is made
+    r = s.stop()
+    assert r["samples"] == 0 and r["engine_clock_MHz"] is None and r["socket_power_W"] is None
+    assert _current_mhz("0: 132Mhz\n1: 2400Mhz *\n") == 2400.0 and _current_mhz("") is None
