@@ -20,6 +20,7 @@ DIAG_MAP_STRIPE = 0x300
 DIAG_MAP_TILES = 0x400
 DIAG_MAP_PIPE = 0x500
 DIAG_MAP_GROUP = 0x600
+FUSED_AUTO, FUSED_OFF, FUSED_ON = 0, 1, 2   # hevc_deblock_sao_*_device: one kernel for both stages / two launches
 DIAG_LIB_PATH = os.path.join(_HERE, "libhevcdbk_diag.so")
 
 # every symbol include/hevc_deblock.h declares (tests check the library exports all of them)
@@ -35,6 +36,7 @@ EXPORTS = [
     "hevcdbk_filter_yuv_file", "hevcdbk_filter_yuv_file_multi",
     "hevcdbk_h265_num_vert_bs", "hevcdbk_h265_num_hor_bs", "hevcdbk_h265_derive_bs_device",
     "hevc_deblocking_filter_h265_device", "hevc_deblocking_filter_h265", "hevc_sao_filter_device",
+    "hevc_deblock_sao_device", "hevc_deblock_sao_h265_device",
 ]
 
 
@@ -176,6 +178,11 @@ def lib():
                                                   C.POINTER(Qp), C.POINTER(H265Params), C.POINTER(Timing)]
         L.hevc_sao_filter_device.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_void_p, C.c_uint, C.c_size_t, C.c_uint,
                                              C.c_void_p, C.c_uint, C.c_size_t, C.c_void_p]
+        L.hevc_deblock_sao_device.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint, C.POINTER(Tables), C.c_void_p, C.c_uint,
+                                              C.c_size_t, C.c_uint, C.c_void_p, C.c_uint, C.c_size_t, C.c_int, C.c_void_p]
+        L.hevc_deblock_sao_h265_device.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_int, C.c_uint, C.POINTER(H265Params),
+                                                   C.c_void_p, C.c_uint, C.c_size_t, C.c_uint, C.c_void_p, C.c_uint, C.c_size_t,
+                                                   C.c_int, C.c_void_p]
         _lib = L
     return _lib
 

@@ -26,6 +26,7 @@ struct hevcdbk_context {
     /* staging for the host-frame operator: pinned host + device, grown on demand */
     Growable pin[3], dev[3];
     Growable pin_bs, dev_bs, dev_map, dev_units;
+    Growable dev_tmp; /* the deblocked planes between the two launches of hevc_deblock_sao_*_device where the fused kernel does not apply */
     std::vector<hipEvent_t> timed_events;
     /* streaming operator: ring of kSeqSlots frames in flight */
     static constexpr int kSeqSlots = 3;

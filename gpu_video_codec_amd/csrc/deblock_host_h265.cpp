@@ -212,11 +212,13 @@ int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, cons
 
 static_assert(sizeof(hevcdbk_sao_ctb) == sizeof(DbkSaoCtb) && sizeof(DbkSaoCtb) == 6, "SAO CTB entry layout");
 
-int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p, const hevcdbk_sao_ctb *params,
-                           unsigned params_stride, size_t params_frame_stride, unsigned ctb_log2, const uint8_t *keep,
-                           unsigned keep_stride, size_t keep_frame_stride, void *hip_stream)
+namespace {
+
+/* validates the SAO operands of `p` and fills `a` (src / dst as in `p`) */
+int sao_args(const hevcdbk_device_planes *p, const hevcdbk_sao_ctb *params, unsigned params_stride, size_t params_frame_stride,
+             unsigned ctb_log2, const uint8_t *keep, unsigned keep_stride, size_t keep_frame_stride, DbkSaoArgs &a)
 {
-    if (!ctx || !p || !p->src || !p->dst || p->src == p->dst || !params) return HEVCDBK_ERR_ARG;
+    if (!p || !p->src || !p->dst || p->src == p->dst || !params) return HEVCDBK_ERR_ARG;
     if (bad_depth(p->bit_depth, p->sample_bytes)) return HEVCDBK_ERR_ARG;
     if (p->plane_w == 0 || p->plane_h == 0 || p->plane_w % 8 != 0 || p->plane_h % 8 != 0) return HEVCDBK_ERR_DIMENSIONS;
     if (ctb_log2 < 3 || ctb_log2 > 6) return HEVCDBK_ERR_ARG;
@@ -226,8 +228,6 @@ int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p,
     if (p->pitch % align != 0 || p->frame_stride % align != 0 || (uintptr_t)p->src % align != 0 || (uintptr_t)p->dst % align != 0)
         return HEVCDBK_ERR_UNSUPPORTED;
     if (p->pitch < (size_t)p->plane_w * p->sample_bytes || p->n_frames > 65535 || p->plane_h > 65535) return HEVCDBK_ERR_ARG;
-    if (int rc = bind(ctx)) return rc;
-    DbkSaoArgs a;
     std::memset(&a, 0, sizeof(a));
     a.src = (const uint8_t *)p->src; a.dst = (uint8_t *)p->dst;
     a.pitch = (long long)p->pitch; a.frame_stride = (long long)p->frame_stride;
@@ -237,8 +237,83 @@ int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p,
     a.params_stride = (int)params_stride; a.params_frame_stride = (long long)params_frame_stride;
     a.ctb_log2 = (int)ctb_log2;
     a.keep = keep; a.keep_stride = (int)keep_stride; a.keep_frame_stride = (long long)keep_frame_stride;
+    return HEVCDBK_OK;
+}
+
+/* the two-launch form of deblocking + SAO: the deblocked planes go through ctx->dev_tmp (same pitch and frame stride) */
+int tmp_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *p, hevcdbk_device_planes &first, hevcdbk_device_planes &second)
+{
+    const size_t bytes = (size_t)p->frame_stride * (p->n_frames ? p->n_frames - 1 : 0) + (size_t)p->pitch * p->plane_h;
+    if (int rc = grow_device(ctx, ctx->dev_tmp, bytes)) return rc;
+    first = *p;
+    first.dst = ctx->dev_tmp.p;
+    second = *p;
+    second.src = ctx->dev_tmp.p;
+    return HEVCDBK_OK;
+}
+
+} /* namespace */
+
+int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p, const hevcdbk_sao_ctb *params,
+                           unsigned params_stride, size_t params_frame_stride, unsigned ctb_log2, const uint8_t *keep,
+                           unsigned keep_stride, size_t keep_frame_stride, void *hip_stream)
+{
+    if (!ctx) return HEVCDBK_ERR_ARG;
+    DbkSaoArgs a;
+    if (int rc = sao_args(p, params, params_stride, params_frame_stride, ctb_log2, keep, keep_stride, keep_frame_stride, a)) return rc;
+    if (int rc = bind(ctx)) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
     return hip_ok(ctx, dbk_launch_sao(a, (int)p->sample_bytes, s), "SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+}
+
+/* ---- deblocking followed by SAO in one call ---------------------------------------------- */
+
+int hevc_deblock_sao_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p, unsigned qp, const hevcdbk_tables *tables,
+                            const hevcdbk_sao_ctb *params, unsigned params_stride, size_t params_frame_stride, unsigned ctb_log2,
+                            const uint8_t *keep, unsigned keep_stride, size_t keep_frame_stride, int fused, void *hip_stream)
+{
+    if (!ctx || (fused != HEVCDBK_FUSED_AUTO && fused != HEVCDBK_FUSED_OFF && fused != HEVCDBK_FUSED_ON)) return HEVCDBK_ERR_ARG;
+    DbkSaoArgs sa;
+    if (int rc = sao_args(p, params, params_stride, params_frame_stride, ctb_log2, keep, keep_stride, keep_frame_stride, sa)) return rc;
+    DbkArgs da;
+    if (int rc = planes_to_args(p, qp, tables, da)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
+    const bool can = dbk_deblock_sao_supports(da, sa, (int)p->sample_bytes, p->is_chroma != 0);
+    if (fused == HEVCDBK_FUSED_ON && !can) return HEVCDBK_ERR_UNSUPPORTED;
+    if (can && fused != HEVCDBK_FUSED_OFF)
+        return hip_ok(ctx, dbk_launch_deblock_sao(da, sa, p->is_chroma != 0, s), "fused deblocking + SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    hevcdbk_device_planes first, second;
+    if (int rc = tmp_planes(ctx, p, first, second)) return rc;
+    if (int rc = planes_to_args(&first, qp, tables, da)) return rc;
+    if (int rc = launch(ctx, da, (int)p->sample_bytes, p->is_chroma != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
+    sa.src = (const uint8_t *)second.src;
+    return hip_ok(ctx, dbk_launch_sao(sa, (int)p->sample_bytes, s), "SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+}
+
+int hevc_deblock_sao_h265_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p, int c_idx, unsigned qp,
+                                 const hevcdbk_h265_params *prm, const hevcdbk_sao_ctb *params, unsigned params_stride,
+                                 size_t params_frame_stride, unsigned ctb_log2, const uint8_t *keep, unsigned keep_stride,
+                                 size_t keep_frame_stride, int fused, void *hip_stream)
+{
+    if (!ctx || (fused != HEVCDBK_FUSED_AUTO && fused != HEVCDBK_FUSED_OFF && fused != HEVCDBK_FUSED_ON)) return HEVCDBK_ERR_ARG;
+    DbkSaoArgs sa;
+    if (int rc = sao_args(p, params, params_stride, params_frame_stride, ctb_log2, keep, keep_stride, keep_frame_stride, sa)) return rc;
+    DbkH265Args h;
+    if (int rc = h265_args(p, c_idx, qp, prm, h)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
+    const bool can = dbk_packed_h265_supports(h, (int)p->sample_bytes, c_idx != 0) &&
+                     dbk_deblock_sao_supports(h.base, sa, (int)p->sample_bytes, c_idx != 0);
+    if (fused == HEVCDBK_FUSED_ON && !can) return HEVCDBK_ERR_UNSUPPORTED;
+    if (can && fused != HEVCDBK_FUSED_OFF)
+        return hip_ok(ctx, dbk_launch_deblock_sao_h265(h, sa, c_idx != 0, s), "fused deblocking + SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    hevcdbk_device_planes first, second;
+    if (int rc = tmp_planes(ctx, p, first, second)) return rc;
+    if (int rc = h265_args(&first, c_idx, qp, prm, h)) return rc;
+    if (int rc = launch_h265(ctx, h, (int)p->sample_bytes, c_idx != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
+    sa.src = (const uint8_t *)second.src;
+    return hip_ok(ctx, dbk_launch_sao(sa, (int)p->sample_bytes, s), "SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
 }
 
 } /* extern "C" */

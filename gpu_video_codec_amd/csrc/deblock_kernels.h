@@ -145,3 +145,17 @@ struct DbkSaoArgs {
     long long keep_frame_stride;
 };
 hipError_t dbk_launch_sao(const DbkSaoArgs &a, int sample_bytes, hipStream_t stream);
+
+/* ---- deblocking + SAO in one kernel (deblock_sao_fused.inc): 8-bit planes, scalar QP; d.src -> s.dst, d.dst and s.src unused ---- */
+struct DbkFusedArgs {
+    DbkArgs d;
+    DbkSaoArgs s;
+};
+struct DbkFusedH265Args {
+    DbkH265Args d;
+    DbkSaoArgs s;
+};
+bool dbk_deblock_sao_supports(const DbkArgs &d, const DbkSaoArgs &s, int sample_bytes, bool chroma);
+hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, bool chroma, hipStream_t stream);
+hipError_t dbk_launch_deblock_sao_h265(const DbkH265Args &h, const DbkSaoArgs &s, bool chroma, hipStream_t stream);
+

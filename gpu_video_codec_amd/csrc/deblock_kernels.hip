@@ -22,6 +22,7 @@
 #include "deblock_packed.h"
 #include "deblock_packed_h265.h"
 #include "deblock_packed16.h"
+#include "sao_packed.h"
 
 /*
  * Every launch goes through hipExtLaunchKernelGGL so that a caller can ask for the NEXT launch to stamp its own start and
@@ -725,6 +726,8 @@ __global__ __launch_bounds__(1024) void dbk_packed16_multi_kernel(const DbkMulti
     }
 }
 
+#include "deblock_sao_fused.inc"
+
 #ifdef HEVCDBK_DIAG
 /* the measured-and-rejected kernels (LDS queue, stripe map, tile map): diagnostic build only, DESIGN.md 4.1 */
 #include "deblock_diag_kernels.inc"
@@ -1138,3 +1141,53 @@ hipError_t dbk_launch_packed_h265(const DbkH265Args &h, int sample_bytes, bool c
 #undef DBK_H265_LAUNCH
     return hipGetLastError();
 }
+
+/* ---- deblocking + SAO in one kernel ---- */
+bool dbk_deblock_sao_supports(const DbkArgs &d, const DbkSaoArgs &s, int sample_bytes, bool chroma)
+{
+    if (sample_bytes != 1 || d.max_v != 255 || s.max_v != 255 || s.band_shift != 3 || d.qp_map || d.by_count != 0) return false;
+    if (!dbk_packed_supports(d, sample_bytes, chroma)) return false;
+    if (d.plane_w != s.plane_w || d.plane_h != s.plane_h || d.n_frames != s.n_frames || d.n_frames > 65535) return false;
+    if ((unsigned long long)s.pitch * (unsigned long long)s.plane_h >= (1ull << 31) || s.pitch % 4 != 0 || s.frame_stride % 4 != 0 ||
+        ((uintptr_t)s.dst % 4) != 0)
+        return false;
+    return (d.plane_h + kFusedTile - 1) / kFusedTile <= 65535;
+}
+
+hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, bool chroma, hipStream_t stream)
+{
+    if (d.n_frames <= 0 || d.nbx <= 0 || d.nby <= 0) return hipSuccess;
+    DbkFusedArgs fa;
+    fa.d = d;
+    fa.s = s;
+    const dim3 grid((d.plane_w + kFusedTile - 1) / kFusedTile, (d.plane_h + kFusedTile - 1) / kFusedTile, d.n_frames), block(kFusedThreads, 1, 1);
+    if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused_kernel<true>), grid, block, kFusedLds, stream, fa);
+    else DBK_LAUNCH_LDS((dbk_sao_fused_kernel<false>), grid, block, kFusedLds, stream, fa);
+    return hipGetLastError();
+}
+
+hipError_t dbk_launch_deblock_sao_h265(const DbkH265Args &h, const DbkSaoArgs &s, bool chroma, hipStream_t stream)
+{
+    if (h.base.n_frames <= 0 || h.base.nbx <= 0 || h.base.nby <= 0) return hipSuccess;
+    DbkFusedH265Args fa;
+    fa.d = h;
+    fa.s = s;
+    { /* the scalar-QP operands of the packed spec-exact kernels, as dbk_launch_packed_h265 derives them */
+        auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        const int sh = h.base.shift, qp = h.qp;
+        fa.d.beta_s = dbk::h265_beta(cl(qp + h.beta_off, 0, 51)) << sh;
+        if (chroma) {
+            fa.d.tc_bs1 = 0;
+            fa.d.tc_bs2 = dbk::h265_tc(cl(dbk::h265_chroma_qp(qp + h.c_qp_offset) + 2 + h.tc_off, 0, 53)) << sh;
+        } else {
+            fa.d.tc_bs1 = dbk::h265_tc(cl(qp + h.tc_off, 0, 53)) << sh;
+            fa.d.tc_bs2 = dbk::h265_tc(cl(qp + 2 + h.tc_off, 0, 53)) << sh;
+        }
+    }
+    const dim3 grid((h.base.plane_w + kFusedTile - 1) / kFusedTile, (h.base.plane_h + kFusedTile - 1) / kFusedTile, h.base.n_frames),
+        block(kFusedThreads, 1, 1);
+    if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused_h265_kernel<true>), grid, block, kFusedLds, stream, fa);
+    else DBK_LAUNCH_LDS((dbk_sao_fused_h265_kernel<false>), grid, block, kFusedLds, stream, fa);
+    return hipGetLastError();
+}
+

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "deblock_kernels.h"
+#include "sao_packed.h"
 
 namespace {
 
@@ -155,11 +156,12 @@ __global__ __launch_bounds__(256) void sao_kernel(const DbkSaoArgs a)
  *     concerned, compiled only into the instantiation for waves that touch the border.
  * About 9 VALU instructions per sample instead of ~20.
  */
-struct SaoRow {
-    uint32_t E0, O0, E1, O1; /* the row's samples as int16 pairs */
-    uint32_t lE0, lE1;       /* (s[-1], s1), (s3, s5): left neighbours of E0, E1 */
-    uint32_t rO0, rO1;       /* (s2, s4), (s6, s8): right neighbours of O0, O1 */
-};
+using sao8::SaoRow;
+using sao8::SaoRaw;
+using sao8::spk;
+using sao8::supk;
+using sao8::s_pk;
+using sao8::s_splat;
 
 typedef uint32_t sao_u32x4 __attribute__((ext_vector_type(4), aligned(4))); /* 16 bytes at a 4-byte-aligned address */
 
@@ -168,59 +170,28 @@ typedef uint32_t sao_u32x4 __attribute__((ext_vector_type(4), aligned(4))); /* 1
 template <bool HALO, bool INNER>
 __device__ __forceinline__ SaoRow sao_load_row(const uint8_t *row, int x, int w)
 {
-    uint32_t lh = 0u, rh = 0u;
-    uint2 c;
+    SaoRaw q;
+    q.lh = q.rh = 0u;
     if constexpr (HALO && INNER) {
-        const sao_u32x4 q = *reinterpret_cast<const sao_u32x4 *>(row + x - 4);
-        lh = q.x; c.x = q.y; c.y = q.z; rh = q.w;
+        const sao_u32x4 v = *reinterpret_cast<const sao_u32x4 *>(row + x - 4);
+        q.lh = v.x; q.cx = v.y; q.cy = v.z; q.rh = v.w;
     } else {
-        c = *reinterpret_cast<const uint2 *>(row + x);
+        const uint2 c = *reinterpret_cast<const uint2 *>(row + x);
+        q.cx = c.x; q.cy = c.y;
         if constexpr (HALO) {
             /* positions outside the row read a valid dword of the row instead; the border masks discard what comes of it */
-            lh = *reinterpret_cast<const uint32_t *>(row + (x >= 4 ? x - 4 : 0));
-            rh = *reinterpret_cast<const uint32_t *>(row + (x + 12 <= w ? x + 8 : w - 4));
+            q.lh = *reinterpret_cast<const uint32_t *>(row + (x >= 4 ? x - 4 : 0));
+            q.rh = *reinterpret_cast<const uint32_t *>(row + (x + 12 <= w ? x + 8 : w - 4));
         }
     }
-    SaoRow r;
-    r.E0 = __builtin_amdgcn_perm(c.x, c.x, 0x0c020c00u);
-    r.O0 = __builtin_amdgcn_perm(c.x, c.x, 0x0c030c01u);
-    r.E1 = __builtin_amdgcn_perm(c.y, c.y, 0x0c020c00u);
-    r.O1 = __builtin_amdgcn_perm(c.y, c.y, 0x0c030c01u);
-    if constexpr (HALO) {
-        r.lE0 = __builtin_amdgcn_perm(c.x, lh, 0x0c050c03u);  /* (lh.b3, c.x.b1) */
-        r.lE1 = __builtin_amdgcn_perm(c.y, c.x, 0x0c050c03u); /* (c.x.b3, c.y.b1) */
-        r.rO0 = __builtin_amdgcn_perm(c.y, c.x, 0x0c040c02u); /* (c.x.b2, c.y.b0) */
-        r.rO1 = __builtin_amdgcn_perm(rh, c.y, 0x0c040c02u);  /* (c.y.b2, rh.b0) */
-    } else {
-        r.lE0 = r.lE1 = r.rO0 = r.rO1 = 0u;
-    }
-    return r;
+    return sao8::unpack<HALO>(q);
 }
 
-typedef short spk __attribute__((vector_size(4)));
-__device__ __forceinline__ spk s_pk(uint32_t v) { return __builtin_bit_cast(spk, v); }
-__device__ __forceinline__ spk s_splat(int v) { return spk{(short)v, (short)v}; }
-typedef unsigned short supk __attribute__((vector_size(4)));
-__device__ __forceinline__ supk s_upk(uint32_t v) { return __builtin_bit_cast(supk, v); }
-/* max(a - b, 0) in both halves: ONE v_pk_sub_u16 with the clamp bit (unsigned saturation) */
-__device__ __forceinline__ supk s_sub_sat(supk a, supk b) { return __builtin_elementwise_sub_sat(a, b); }
-
-/* rec + offset[index], clipped to 8 bit: tab_lo / tab_hi hold the five offset bytes + 128.  rec + t is non-negative, so
- * the lower clip is the saturation of the unsigned subtraction of the bias */
 __device__ __forceinline__ uint32_t sao_apply(uint32_t rec, uint32_t idx, uint32_t tab_lo, uint32_t tab_hi)
 {
-    const uint32_t t = __builtin_amdgcn_perm(tab_hi, tab_lo, idx | 0x0c000c00u);
-    const supk v = s_sub_sat(s_upk(rec) + s_upk(t), supk{128, 128});
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, supk{255, 255}));
+    return sao8::apply(rec, idx, tab_lo, tab_hi);
 }
-/* edge index of both samples of `rec` against the neighbour pairs a and b: 0..4, 2 = neither minimum nor maximum;
- * clamp(rec + 1 - a, 0, 2) = min(saturating (rec + 1) - a, 2) */
-__device__ __forceinline__ uint32_t sao_edge_idx(uint32_t rec, uint32_t a, uint32_t b)
-{
-    const supk r1 = s_upk(rec) + supk{1, 1}, two = supk{2, 2};
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(s_sub_sat(r1, s_upk(a)), two) +
-                                            __builtin_elementwise_min(s_sub_sat(r1, s_upk(b)), two));
-}
+__device__ __forceinline__ uint32_t sao_edge_idx(uint32_t rec, uint32_t a, uint32_t b) { return sao8::edge_idx(rec, a, b); }
 
 template <bool BORDER>
 __device__ __forceinline__ void sao8_edge_block(const DbkSaoArgs &a, const uint8_t *src, uint8_t *dst, int x, int y0, int cls,
@@ -300,10 +271,9 @@ __global__ __launch_bounds__(256) void sao8_kernel(const DbkSaoArgs a)
     if (c.type == 1) { /* band offset: bandTable[(k + sao_band_position) & 31] = k + 1; index min(k, 4), entry 4 = no offset */
         const uint32_t tab_lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (b(c.offset[2]) << 16) | (b(c.offset[3]) << 24), tab_hi = b(0);
         const spk pos = s_splat((int)c.cls);
-        typedef unsigned short upk __attribute__((vector_size(4)));
         auto band = [&](uint32_t rec) {
             const spk k = ((s_pk(rec) >> 3) - pos) & s_splat(31);              /* 8 bit: bandShift = bitDepth - 5 = 3 */
-            const upk k4 = __builtin_elementwise_min(__builtin_bit_cast(upk, k), upk{4, 4});
+            const supk k4 = __builtin_elementwise_min(__builtin_bit_cast(supk, k), supk{4, 4});
             return sao_apply(rec, __builtin_bit_cast(uint32_t, k4), tab_lo, tab_hi);
         };
 #pragma unroll

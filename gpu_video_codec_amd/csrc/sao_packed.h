@@ -1,0 +1,153 @@
+/*
+ * sao_packed.h -- sample adaptive offset (H.265 8.7.3) of one 8x8 block of 8-bit samples held in registers, packed-int16
+ * arithmetic (see sao.hip for the scheme).  Shared by the SAO pass (sao.hip) and the fused deblocking + SAO kernel
+ * (deblock_sao_fused.inc): the block's ten rows y0-1 .. y0+8 arrive as SaoRaw (samples x-4 .. x+11 each), from HBM or from
+ * the workgroup's LDS tile, and the eight output rows leave through a store functor.  Device code only.
+ */
+#pragma once
+#include <stdint.h>
+
+#include "deblock_kernels.h"
+
+namespace sao8 {
+
+struct SaoRow {
+    uint32_t E0, O0, E1, O1; /* the row's samples as int16 pairs: (s0, s2), (s1, s3), (s4, s6), (s5, s7) */
+    uint32_t lE0, lE1;       /* (s[-1], s1), (s3, s5): left neighbours of E0, E1 */
+    uint32_t rO0, rO1;       /* (s2, s4), (s6, s8): right neighbours of O0, O1 */
+};
+
+/* a row as it comes from memory: samples x-4 .. x+11 (lh | cx cy | rh); lh / rh are only looked at by the classes with
+ * horizontal neighbours */
+struct SaoRaw {
+    uint32_t lh, cx, cy, rh;
+};
+
+template <bool HALO>
+__device__ __forceinline__ SaoRow unpack(const SaoRaw &q)
+{
+    SaoRow r;
+    r.E0 = __builtin_amdgcn_perm(q.cx, q.cx, 0x0c020c00u);
+    r.O0 = __builtin_amdgcn_perm(q.cx, q.cx, 0x0c030c01u);
+    r.E1 = __builtin_amdgcn_perm(q.cy, q.cy, 0x0c020c00u);
+    r.O1 = __builtin_amdgcn_perm(q.cy, q.cy, 0x0c030c01u);
+    if constexpr (HALO) {
+        r.lE0 = __builtin_amdgcn_perm(q.cx, q.lh, 0x0c050c03u); /* (lh.b3, cx.b1) */
+        r.lE1 = __builtin_amdgcn_perm(q.cy, q.cx, 0x0c050c03u); /* (cx.b3, cy.b1) */
+        r.rO0 = __builtin_amdgcn_perm(q.cy, q.cx, 0x0c040c02u); /* (cx.b2, cy.b0) */
+        r.rO1 = __builtin_amdgcn_perm(q.rh, q.cy, 0x0c040c02u); /* (cy.b2, rh.b0) */
+    } else {
+        r.lE0 = r.lE1 = r.rO0 = r.rO1 = 0u;
+    }
+    return r;
+}
+
+typedef short spk __attribute__((vector_size(4)));
+typedef unsigned short supk __attribute__((vector_size(4)));
+__device__ __forceinline__ spk s_pk(uint32_t v) { return __builtin_bit_cast(spk, v); }
+__device__ __forceinline__ spk s_splat(int v) { return spk{(short)v, (short)v}; }
+__device__ __forceinline__ supk s_upk(uint32_t v) { return __builtin_bit_cast(supk, v); }
+/* max(a - b, 0) in both halves: ONE v_pk_sub_u16 with the clamp bit (unsigned saturation) */
+__device__ __forceinline__ supk s_sub_sat(supk a, supk b) { return __builtin_elementwise_sub_sat(a, b); }
+
+/* rec + offset[index], clipped to 8 bit: tab_lo / tab_hi hold the five offset bytes + 128.  rec + t is non-negative, so
+ * the lower clip is the saturation of the unsigned subtraction of the bias */
+__device__ __forceinline__ uint32_t apply(uint32_t rec, uint32_t idx, uint32_t tab_lo, uint32_t tab_hi)
+{
+    const uint32_t t = __builtin_amdgcn_perm(tab_hi, tab_lo, idx | 0x0c000c00u);
+    const supk v = s_sub_sat(s_upk(rec) + s_upk(t), supk{128, 128});
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, supk{255, 255}));
+}
+/* edge index of both samples of `rec` against the neighbour pairs a and b: 0..4, 2 = neither minimum nor maximum;
+ * clamp(rec + 1 - a, 0, 2) = min(saturating (rec + 1) - a, 2) */
+__device__ __forceinline__ uint32_t edge_idx(uint32_t rec, uint32_t a, uint32_t b)
+{
+    const supk r1 = s_upk(rec) + supk{1, 1}, two = supk{2, 2};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(s_sub_sat(r1, s_upk(a)), two) +
+                                            __builtin_elementwise_min(s_sub_sat(r1, s_upk(b)), two));
+}
+
+/* the 8 output rows of an edge-offset block from its ten raw rows, class CLS of Table 8-13: 0 (-1,0)/(1,0); 1 (0,-1)/(0,1);
+ * 2 (-1,-1)/(1,1); 3 (1,-1)/(-1,1).  BORDER: the block may touch the picture border (x, y0 = its position, w x h the picture):
+ * a sample with a neighbour outside the picture gets no offset (8.7.3.2), whatever the raw rows hold there.
+ * store(r, lo, hi) takes output row r as its two dwords. */
+template <int CLS, bool BORDER, typename Store>
+__device__ __forceinline__ void edge_rows(const SaoRaw (&raw)[10], const Store &store, int x, int y0, int w, int h, uint32_t tab_lo,
+                                          uint32_t tab_hi)
+{
+    constexpr bool horizontal = CLS != 1, vertical = CLS != 0;
+    SaoRow up = unpack<horizontal>(raw[0]), mid = unpack<horizontal>(raw[1]), dn;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int y = y0 + r;
+        dn = unpack<horizontal>(raw[r + 2]);
+        uint32_t i0, i1, i2, i3; /* indices of E0, O0, E1, O1 */
+        if constexpr (CLS == 0) {
+            i0 = edge_idx(mid.E0, mid.lE0, mid.O0);
+            i1 = edge_idx(mid.O0, mid.E0, mid.rO0);
+            i2 = edge_idx(mid.E1, mid.lE1, mid.O1);
+            i3 = edge_idx(mid.O1, mid.E1, mid.rO1);
+        } else if constexpr (CLS == 1) {
+            i0 = edge_idx(mid.E0, up.E0, dn.E0);
+            i1 = edge_idx(mid.O0, up.O0, dn.O0);
+            i2 = edge_idx(mid.E1, up.E1, dn.E1);
+            i3 = edge_idx(mid.O1, up.O1, dn.O1);
+        } else if constexpr (CLS == 2) {
+            i0 = edge_idx(mid.E0, up.lE0, dn.O0);
+            i1 = edge_idx(mid.O0, up.E0, dn.rO0);
+            i2 = edge_idx(mid.E1, up.lE1, dn.O1);
+            i3 = edge_idx(mid.O1, up.E1, dn.rO1);
+        } else {
+            i0 = edge_idx(mid.E0, up.O0, dn.lE0);
+            i1 = edge_idx(mid.O0, up.rO0, dn.E0);
+            i2 = edge_idx(mid.E1, up.O1, dn.lE1);
+            i3 = edge_idx(mid.O1, up.rO1, dn.E1);
+        }
+        if constexpr (BORDER) {
+            if (vertical && (y == 0 || y == h - 1)) i0 = i1 = i2 = i3 = 0x00020002u;
+            if (horizontal && x == 0) i0 = (i0 & 0xffff0000u) | 2u;              /* sample 0: low half of E0 */
+            if (horizontal && x + 8 == w) i3 = (i3 & 0x0000ffffu) | 0x00020000u; /* sample 7: high half of O1 */
+        }
+        const uint32_t e0 = apply(mid.E0, i0, tab_lo, tab_hi), o0 = apply(mid.O0, i1, tab_lo, tab_hi);
+        const uint32_t e1 = apply(mid.E1, i2, tab_lo, tab_hi), o1 = apply(mid.O1, i3, tab_lo, tab_hi);
+        store(r, e0 | (o0 << 8), e1 | (o1 << 8));
+        up = mid;
+        mid = dn;
+    }
+}
+
+/* one 8x8 block given its ten raw rows: not applied / kept (copy), band offset, or edge offset */
+template <bool BORDER, typename Store>
+__device__ __forceinline__ void block(const SaoRaw (&raw)[10], const Store &store, int x, int y0, int w, int h, const DbkSaoCtb &c, bool kept)
+{
+    if (kept || c.type == 0 || c.type > 2) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) store(r, raw[r + 1].cx, raw[r + 1].cy);
+        return;
+    }
+    auto b = [](int v) { return (uint32_t)(v + 128) & 0xffu; };
+    if (c.type == 1) { /* band offset: bandTable[(k + sao_band_position) & 31] = k + 1; index min(k, 4), entry 4 = no offset */
+        const uint32_t tab_lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (b(c.offset[2]) << 16) | (b(c.offset[3]) << 24), tab_hi = b(0);
+        const spk pos = s_splat((int)c.cls);
+        auto band = [&](uint32_t rec) {
+            const spk k = ((s_pk(rec) >> 3) - pos) & s_splat(31); /* 8 bit: bandShift = bitDepth - 5 = 3 */
+            const supk k4 = __builtin_elementwise_min(__builtin_bit_cast(supk, k), supk{4, 4});
+            return apply(rec, __builtin_bit_cast(uint32_t, k4), tab_lo, tab_hi);
+        };
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const SaoRow m = unpack<false>(raw[r + 1]);
+            store(r, band(m.E0) | (band(m.O0) << 8), band(m.E1) | (band(m.O1) << 8));
+        }
+        return;
+    }
+    /* edge offset: index 0 -> SaoOffsetVal[1], 1 -> [2], 2 -> none, 3 -> [3], 4 -> [4] */
+    const uint32_t tab_lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (b(0) << 16) | (b(c.offset[2]) << 24), tab_hi = b(c.offset[3]);
+    const int cls = c.cls & 3;
+    if (cls == 0) edge_rows<0, BORDER>(raw, store, x, y0, w, h, tab_lo, tab_hi);
+    else if (cls == 1) edge_rows<1, BORDER>(raw, store, x, y0, w, h, tab_lo, tab_hi);
+    else if (cls == 2) edge_rows<2, BORDER>(raw, store, x, y0, w, h, tab_lo, tab_hi);
+    else edge_rows<3, BORDER>(raw, store, x, y0, w, h, tab_lo, tab_hi);
+}
+
+} /* namespace sao8 */

@@ -325,6 +325,23 @@ class Context:
         _chk(_lib.lib().hevc_sao_filter_device(self.handle, C.byref(planes), params_ptr, params_stride, params_frame_stride,
                                                ctb_log2, keep_ptr, keep_stride, keep_frame_stride, None), self.handle)
 
+    def deblock_sao_device(self, planes, qp, params_ptr, params_stride, ctb_log2, *, params_frame_stride=0, keep_ptr=None,
+                           keep_stride=0, keep_frame_stride=0, tc_table=None, beta_table=None, fused=_lib.FUSED_AUTO):
+        """hevc_deblock_sao_device: reference-exact deblocking followed by SAO, src -> dst, one kernel where it applies."""
+        t, _k = _tables(tc_table, beta_table)
+        _chk(_lib.lib().hevc_deblock_sao_device(self.handle, C.byref(planes), int(qp), None if t is None else C.byref(t), params_ptr,
+                                                params_stride, params_frame_stride, ctb_log2, keep_ptr, keep_stride, keep_frame_stride,
+                                                fused, None), self.handle)
+
+    def deblock_sao_h265_device(self, planes, qp, params_ptr, params_stride, ctb_log2, *, c_idx=0, tc_offset_div2=0,
+                                beta_offset_div2=0, cb_qp_offset=0, cr_qp_offset=0, params_frame_stride=0, keep_ptr=None,
+                                keep_stride=0, keep_frame_stride=0, fused=_lib.FUSED_AUTO):
+        """hevc_deblock_sao_h265_device: spec-exact deblocking (8.7.2) followed by SAO (8.7.3), src -> dst."""
+        prm = _lib.H265Params(tc_offset_div2, beta_offset_div2, cb_qp_offset, cr_qp_offset)
+        _chk(_lib.lib().hevc_deblock_sao_h265_device(self.handle, C.byref(planes), c_idx, int(qp), C.byref(prm), params_ptr, params_stride,
+                                                     params_frame_stride, ctb_log2, keep_ptr, keep_stride, keep_frame_stride, fused,
+                                                     None), self.handle)
+
     def filter_device_planes(self, planes_list, qp, *, tc_table=None, beta_table=None, variant=KERNEL_AUTO):
         """hevc_deblocking_filter_device_planes: Y, U, V of a batch in one call (one fused launch where that applies)."""
         arr = (_lib.DevicePlanes * len(planes_list))(*planes_list)

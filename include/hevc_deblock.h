@@ -361,6 +361,31 @@ HEVCDBK_API int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_devic
                            unsigned params_stride, size_t params_frame_stride, unsigned ctb_log2, const uint8_t *keep,
                            unsigned keep_stride, size_t keep_frame_stride, void *hip_stream);
 
+/*
+ * Deblocking followed by SAO in ONE call, src -> dst (they must differ), of planes that live in HBM -- the in-loop chain of
+ * a decoder.  Operands as for hevc_deblocking_filter_device (reference-exact mode: `qp`, `tables`, the
+ * planes' bS arrays) resp. hevc_deblocking_filter_h265_device (spec-exact mode: `c_idx`, `qp`, `h265_params`, the planes'
+ * 4-sample-granular bS arrays) and for hevc_sao_filter_device (`params` ... `keep_frame_stride`, all DEVICE memory).
+ * For 8-bit planes with a scalar QP both stages run in ONE kernel: a workgroup deblocks the offset blocks of a 128 x 128 tile
+ * (plus a one-sample rim) into LDS and applies SAO from there, so every sample is read from HBM once and written once and the
+ * deblocked picture never exists in memory.  Other operands (16-bit containers, QP maps) run as two launches through a
+ * scratch plane owned by the context.  `fused`: HEVCDBK_FUSED_AUTO picks, _OFF forces the two launches (same bytes; for
+ * A/B runs), _ON returns HEVCDBK_ERR_UNSUPPORTED where the fused kernel does not apply.  Parity: the deblocking stage as for
+ * its own entry points; SAO against oracle/h265_oracle.c only ("parity unpinned").
+ */
+#define HEVCDBK_FUSED_AUTO 0
+#define HEVCDBK_FUSED_OFF  1
+#define HEVCDBK_FUSED_ON   2
+HEVCDBK_API int hevc_deblock_sao_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned qp,
+                                        const hevcdbk_tables *tables, const hevcdbk_sao_ctb *params, unsigned params_stride,
+                                        size_t params_frame_stride, unsigned ctb_log2, const uint8_t *keep, unsigned keep_stride,
+                                        size_t keep_frame_stride, int fused, void *hip_stream);
+HEVCDBK_API int hevc_deblock_sao_h265_device(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, int c_idx, unsigned qp,
+                                             const hevcdbk_h265_params *h265_params, const hevcdbk_sao_ctb *params,
+                                             unsigned params_stride, size_t params_frame_stride, unsigned ctb_log2,
+                                             const uint8_t *keep, unsigned keep_stride, size_t keep_frame_stride, int fused,
+                                             void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

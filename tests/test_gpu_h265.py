@@ -249,6 +249,74 @@ def test_sao_on_device(ctx, h265):
     b.free()
 
 
+def test_deblock_sao_one_call(ctx, h265, oracle):
+    """hevc_deblock_sao_device / hevc_deblock_sao_h265_device: deblocking followed by SAO, src -> dst, as ONE kernel (a
+    workgroup deblocks the offset blocks of a 128 x 128 tile into LDS and applies SAO from there) and as two launches through
+    the context's scratch plane: both equal the oracle chain SAO(deblock(x)).  Geometries around the tile edge (127 / 128 /
+    129 blocks would be 1016 / 1024 / 1032 samples), planes smaller than a tile, luma and chroma, CTB sizes 16 / 32 / 64, keep
+    map, per-frame bS and parameters, pitched planes; 10 bit takes the two-launch form behind the same call and the fused
+    selector refuses it."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    rng = np.random.RandomState(77)
+    cases = [(128, 128, 8, 6, False, None), (136, 120, 8, 6, False, None), (1032, 264, 8, 6, False, 1056), (16, 8, 8, 4, False, None),
+             (3840, 144, 8, 6, False, None), (264, 392, 8, 5, True, None), (1024, 128, 8, 4, True, None), (520, 136, 8, 5, False, None),
+             (256, 136, 10, 6, False, None)]
+    for (w, h, bd, ctb_log2, chroma, pitch) in cases:
+        sb = 1 if bd == 8 else 2
+        n = 2
+        frames = np.stack([synth.blocky_plane(w, h, seed=3 * w + i, bit_depth=bd) for i in range(n)])
+        frames = np.clip(frames.astype(np.int32) + rng.randint(-3, 4, frames.shape), 0, (1 << bd) - 1).astype(frames.dtype)
+        frames[0, : h // 2, : w // 2] = rng.randint(0, 1 << bd, (h // 2, w // 2))   # noise: clipping, 'off' segments
+        prm = np.stack([h265.random_sao_params(w, h, ctb_log2, seed=w + 10 * i, bit_depth=bd) for i in range(n)])
+        keep = (rng.randint(0, 6, (n, h // 8, w // 8)) == 0).astype(np.uint8)
+        dp, dk = ctx.alloc(prm.nbytes), ctx.alloc(keep.nbytes)
+        dp.upload(prm.view(np.uint8).ravel())
+        dk.upload(keep.ravel())
+        kw = dict(params_frame_stride=prm.shape[1] * prm.shape[2], keep_ptr=dk.ptr, keep_stride=w // 8, keep_frame_stride=(h // 8) * (w // 8))
+        qp = 37
+        # ---- reference-exact deblocking + SAO
+        bss = [oracle.lcg_bs(w, h, 9), oracle.default_bs(w, h)]
+        b = deblock.DeviceBatch(ctx, w, h, n, bit_depth=bd, is_chroma=chroma, pitch=None if pitch is None else pitch * sb)
+        b.upload_all(frames, fill=0x5A if bd == 8 else 0x15A)
+        for f in range(n):
+            b.set_bs(f, *bss[f])
+        want = [h265.sao_plane(oracle.filter_plane(frames[f], qp, is_chroma=chroma, bit_depth=bd, vert_bs=bss[f][0], hor_bs=bss[f][1]),
+                               prm[f], ctb_log2, bit_depth=bd, keep=keep[f]) for f in range(n)]
+        modes = (_lib.FUSED_AUTO, _lib.FUSED_OFF) + ((_lib.FUSED_ON,) if bd == 8 else ())
+        for fused in modes:
+            b.dst.upload(np.zeros(b.frame_bytes * n, np.uint8))
+            ctx.deblock_sao_device(b.planes(), qp, dp.ptr, prm.shape[2], ctb_log2, fused=fused, **kw)
+            ctx.synchronize()
+            for f in range(n):
+                assert np.array_equal(b.download_frame(f), want[f]), ("ref", w, h, bd, ctb_log2, chroma, fused, f)
+                assert np.array_equal(b.download_frame(f, "src"), frames[f])
+        if bd != 8:
+            with pytest.raises(_lib.DeblockError) as e:
+                ctx.deblock_sao_device(b.planes(), qp, dp.ptr, prm.shape[2], ctb_log2, fused=_lib.FUSED_ON, **kw)
+            assert e.value.code == _lib.ERR_UNSUPPORTED
+        # ---- spec-exact deblocking + SAO
+        vb = (rng.randint(0, 3, h265.num_vert_bs(w, h)) | (rng.randint(0, 10, h265.num_vert_bs(w, h)) == 0) * 4).astype(np.uint8)
+        hb = (rng.randint(0, 3, h265.num_hor_bs(w, h)) | (rng.randint(0, 10, h265.num_hor_bs(w, h)) == 0) * 8).astype(np.uint8)
+        dv, dh = ctx.alloc(vb.size), ctx.alloc(hb.size)
+        dv.upload(vb)
+        dh.upload(hb)
+        p = b.planes()
+        p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
+        offs = dict(tc_offset_div2=2, beta_offset_div2=-1)
+        c_idx, cq = (1, 3) if chroma else (0, 0)
+        want = [h265.sao_plane(h265.filter_plane(frames[f], qp, vb, hb, c_idx=c_idx, bit_depth=bd, c_qp_offset=cq, **offs),
+                               prm[f], ctb_log2, bit_depth=bd, keep=keep[f]) for f in range(n)]
+        for fused in modes:
+            b.dst.upload(np.zeros(b.frame_bytes * n, np.uint8))
+            ctx.deblock_sao_h265_device(p, qp, dp.ptr, prm.shape[2], ctb_log2, c_idx=c_idx, cb_qp_offset=cq, fused=fused, **offs, **kw)
+            ctx.synchronize()
+            for f in range(n):
+                assert np.array_equal(b.download_frame(f), want[f]), ("spec", w, h, bd, ctb_log2, chroma, fused, f)
+        for x in (dp, dk, dv, dh):
+            x.free()
+        b.free()
+
+
 def test_random_geometry_sweep_both_modes(ctx, h265, oracle):
     """Seeded sweep over plane geometries (widths around the wave / workgroup boundaries included), both filter modes,
     both kernels, 8 and 10 bit, luma and chroma, in place and src -> dst: any indexing slip at a frame edge, a partial wave
