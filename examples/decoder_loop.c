@@ -1,7 +1,7 @@
 /*
  * decoder_loop.c -- plain-C sketch of a decoder's in-loop stage on top of include/hevc_deblock.h: per picture, derive bS
- * from the prediction data on the GPU (H.265 8.7.2.4), deblock Y / Cb / Cr in place (8.7.2), then SAO into the output
- * picture (8.7.3).  Everything stays in HBM; the caller owns all buffers.  Built by the CPU test-suite with
+ * from the prediction data on the GPU (H.265 8.7.2.4), deblock + SAO the luma plane into the output picture in one kernel
+ * (8.7.2 + 8.7.3), deblock Cb / Cr in place.  Everything stays in HBM; the caller owns all buffers.  Built by the CPU test-suite with
  * `gcc -std=c99 -pedantic -Wall -Werror` to prove that the header is a C header; run it on a machine with an MI355X:
  *
  *   gcc -std=c99 -Iinclude examples/decoder_loop.c -Lgpu_video_codec_amd -lhevcdbk -Wl,-rpath,$PWD/gpu_video_codec_amd -o decoder_loop
@@ -31,7 +31,7 @@ int main(void)
         return 2;
     }
 
-    /* picture planes (deblocked in place), SAO output planes, prediction data, bS arrays, SAO parameters: all in HBM */
+    /* picture planes, the luma output plane, prediction data, bS arrays, SAO parameters: all in HBM */
     void *y, *cb, *cr, *y_out, *flags, *mv0, *mv1, *ref0, *ref1, *vbs, *hbs, *cvbs, *chbs, *sao;
     CHECK(hevcdbk_device_malloc(ctx, (size_t)W * H, &y));
     CHECK(hevcdbk_device_malloc(ctx, (size_t)CW * CH, &cb));
@@ -65,27 +65,24 @@ int main(void)
     u.ref0 = (const int32_t *)ref0; u.ref1 = (const int32_t *)ref1;
     CHECK(hevcdbk_h265_derive_bs_device(ctx, &u, W, H, (uint8_t *)vbs, (uint8_t *)hbs, (uint8_t *)cvbs, (uint8_t *)chbs, NULL));
 
-    /* 8.7.2: the three planes, in place */
+    /* 8.7.2 + 8.7.3, luma: reconstruction -> output picture in ONE kernel (deblocked samples go from the first stage to the
+     * second through LDS; the deblocked picture never exists in memory) */
     hevcdbk_h265_params prm;
     memset(&prm, 0, sizeof(prm));
     hevcdbk_device_planes p;
     memset(&p, 0, sizeof(p));
     p.n_frames = 1; p.bit_depth = 8; p.sample_bytes = 1;
-    p.src = p.dst = y; p.pitch = W; p.frame_stride = (size_t)W * H; p.plane_w = W; p.plane_h = H;
+    p.src = y; p.dst = y_out; p.pitch = W; p.frame_stride = (size_t)W * H; p.plane_w = W; p.plane_h = H;
     p.vert_bs = (const uint8_t *)vbs; p.hor_bs = (const uint8_t *)hbs;
-    CHECK(hevc_deblocking_filter_h265_device(ctx, &p, 0, 32, &prm, HEVCDBK_KERNEL_AUTO, NULL));
+    CHECK(hevc_deblock_sao_h265_device(ctx, &p, 0, 32, &prm, (const hevcdbk_sao_ctb *)sao, ctbs_x, 0, 6, NULL, 0, 0,
+                                       HEVCDBK_FUSED_AUTO, NULL));
+    /* 8.7.2, chroma: in place (a decoder with chroma SAO enabled would use the same fused entry with 32-sample CTBs) */
     p.is_chroma = 1; p.pitch = CW; p.frame_stride = (size_t)CW * CH; p.plane_w = CW; p.plane_h = CH;
     p.vert_bs = (const uint8_t *)cvbs; p.hor_bs = (const uint8_t *)chbs;
     p.src = p.dst = cb;
     CHECK(hevc_deblocking_filter_h265_device(ctx, &p, 1, 32, &prm, HEVCDBK_KERNEL_AUTO, NULL));
     p.src = p.dst = cr;
     CHECK(hevc_deblocking_filter_h265_device(ctx, &p, 2, 32, &prm, HEVCDBK_KERNEL_AUTO, NULL));
-
-    /* 8.7.3: luma, deblocked picture -> output picture */
-    memset(&p, 0, sizeof(p));
-    p.n_frames = 1; p.bit_depth = 8; p.sample_bytes = 1;
-    p.src = y; p.dst = y_out; p.pitch = W; p.frame_stride = (size_t)W * H; p.plane_w = W; p.plane_h = H;
-    CHECK(hevc_sao_filter_device(ctx, &p, (const hevcdbk_sao_ctb *)sao, ctbs_x, 0, 6, NULL, 0, 0, NULL));
     CHECK(hevcdbk_synchronize(ctx));
     printf("one %ux%u picture through bS derivation, deblocking and SAO on the GPU\n", W, H);
 

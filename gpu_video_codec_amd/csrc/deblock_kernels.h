@@ -147,13 +147,22 @@ struct DbkSaoArgs {
 hipError_t dbk_launch_sao(const DbkSaoArgs &a, int sample_bytes, hipStream_t stream);
 
 /* ---- deblocking + SAO in one kernel (deblock_sao_fused.inc): 8-bit planes, scalar QP; d.src -> s.dst, d.dst and s.src unused ---- */
+/* tile numbering of the fused kernel (filled by its launchers): a 1-D grid, workgroups renumbered so that each XCD gets a
+ * contiguous range of tiles (row-major inside a frame: tiles that share cache lines and rim rows meet in one L2) */
+struct DbkFusedGrid {
+    uint32_t tiles_x, tiles_per_frame, total; /* total = tiles_per_frame * n_frames */
+    uint32_t magic_tpf, magic_tx;             /* floor(2^32/d)+1 reciprocals */
+    uint32_t per_xcd;                         /* grid size / 8 */
+};
 struct DbkFusedArgs {
     DbkArgs d;
     DbkSaoArgs s;
+    DbkFusedGrid g;
 };
 struct DbkFusedH265Args {
     DbkH265Args d;
     DbkSaoArgs s;
+    DbkFusedGrid g;
 };
 bool dbk_deblock_sao_supports(const DbkArgs &d, const DbkSaoArgs &s, int sample_bytes, bool chroma);
 hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, bool chroma, hipStream_t stream);

@@ -1151,7 +1151,23 @@ bool dbk_deblock_sao_supports(const DbkArgs &d, const DbkSaoArgs &s, int sample_
     if ((unsigned long long)s.pitch * (unsigned long long)s.plane_h >= (1ull << 31) || s.pitch % 4 != 0 || s.frame_stride % 4 != 0 ||
         ((uintptr_t)s.dst % 4) != 0)
         return false;
-    return (d.plane_h + kFusedTile - 1) / kFusedTile <= 65535;
+    const unsigned long long tiles = (unsigned long long)((d.plane_w + kFusedTile - 1) / kFusedTile) * ((d.plane_h + kFusedTile - 1) / kFusedTile);
+    return tiles * (unsigned long long)d.n_frames + 8 < (1ull << 31) && tiles * tiles < (1ull << 32) &&
+           (tiles * d.n_frames + 8) * tiles < (1ull << 32); /* exact reciprocal divisions: dividend < 2^32 / divisor */
+}
+
+/* 1-D grid of the fused kernel, a multiple of 8 workgroups */
+static unsigned fused_grid(int plane_w, int plane_h, int n_frames, DbkFusedGrid &g)
+{
+    const unsigned long long tx = (plane_w + kFusedTile - 1) / kFusedTile, ty = (plane_h + kFusedTile - 1) / kFusedTile, tpf = tx * ty;
+    g.tiles_x = (uint32_t)tx;
+    g.tiles_per_frame = (uint32_t)tpf;
+    g.total = (uint32_t)(tpf * n_frames);
+    g.magic_tpf = tpf <= 1 ? 0u : (uint32_t)((1ull << 32) / tpf + 1ull);
+    g.magic_tx = tx <= 1 ? 0u : (uint32_t)((1ull << 32) / tx + 1ull);
+    const unsigned grid = (g.total + 7u) / 8u * 8u;
+    g.per_xcd = grid / 8u;
+    return grid;
 }
 
 hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, bool chroma, hipStream_t stream)
@@ -1160,7 +1176,7 @@ hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, bool ch
     DbkFusedArgs fa;
     fa.d = d;
     fa.s = s;
-    const dim3 grid((d.plane_w + kFusedTile - 1) / kFusedTile, (d.plane_h + kFusedTile - 1) / kFusedTile, d.n_frames), block(kFusedThreads, 1, 1);
+    const dim3 grid(fused_grid(d.plane_w, d.plane_h, d.n_frames, fa.g), 1, 1), block(kFusedThreads, 1, 1);
     if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused_kernel<true>), grid, block, kFusedLds, stream, fa);
     else DBK_LAUNCH_LDS((dbk_sao_fused_kernel<false>), grid, block, kFusedLds, stream, fa);
     return hipGetLastError();
@@ -1184,8 +1200,7 @@ hipError_t dbk_launch_deblock_sao_h265(const DbkH265Args &h, const DbkSaoArgs &s
             fa.d.tc_bs2 = dbk::h265_tc(cl(qp + 2 + h.tc_off, 0, 53)) << sh;
         }
     }
-    const dim3 grid((h.base.plane_w + kFusedTile - 1) / kFusedTile, (h.base.plane_h + kFusedTile - 1) / kFusedTile, h.base.n_frames),
-        block(kFusedThreads, 1, 1);
+    const dim3 grid(fused_grid(h.base.plane_w, h.base.plane_h, h.base.n_frames, fa.g), 1, 1), block(kFusedThreads, 1, 1);
     if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused_h265_kernel<true>), grid, block, kFusedLds, stream, fa);
     else DBK_LAUNCH_LDS((dbk_sao_fused_h265_kernel<false>), grid, block, kFusedLds, stream, fa);
     return hipGetLastError();

@@ -1,8 +1,8 @@
 /*
  * sao_packed.h -- sample adaptive offset (H.265 8.7.3) of one 8x8 block of 8-bit samples held in registers, packed-int16
  * arithmetic (see sao.hip for the scheme).  Shared by the SAO pass (sao.hip) and the fused deblocking + SAO kernel
- * (deblock_sao_fused.inc): the block's ten rows y0-1 .. y0+8 arrive as SaoRaw (samples x-4 .. x+11 each), from HBM or from
- * the workgroup's LDS tile, and the eight output rows leave through a store functor.  Device code only.
+ * (deblock_sao_fused.inc): the block's ten rows y0-1 .. y0+8 arrive as SaoRaw (samples x-4 .. x+11 each) through a fetch functor
+ * -- from the workgroup's LDS tile, row by row as they are needed -- and the eight output rows leave through a store functor.  Device code only.
  */
 #pragma once
 #include <stdint.h>
@@ -71,16 +71,16 @@ __device__ __forceinline__ uint32_t edge_idx(uint32_t rec, uint32_t a, uint32_t 
  * 2 (-1,-1)/(1,1); 3 (1,-1)/(-1,1).  BORDER: the block may touch the picture border (x, y0 = its position, w x h the picture):
  * a sample with a neighbour outside the picture gets no offset (8.7.3.2), whatever the raw rows hold there.
  * store(r, lo, hi) takes output row r as its two dwords. */
-template <int CLS, bool BORDER, typename Store>
-__device__ __forceinline__ void edge_rows(const SaoRaw (&raw)[10], const Store &store, int x, int y0, int w, int h, uint32_t tab_lo,
+template <int CLS, bool BORDER, typename Fetch, typename Store>
+__device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store, int x, int y0, int w, int h, uint32_t tab_lo,
                                           uint32_t tab_hi)
 {
     constexpr bool horizontal = CLS != 1, vertical = CLS != 0;
-    SaoRow up = unpack<horizontal>(raw[0]), mid = unpack<horizontal>(raw[1]), dn;
+    SaoRow up = unpack<horizontal>(fetch(0)), mid = unpack<horizontal>(fetch(1)), dn;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int y = y0 + r;
-        dn = unpack<horizontal>(raw[r + 2]);
+        dn = unpack<horizontal>(fetch(r + 2));
         uint32_t i0, i1, i2, i3; /* indices of E0, O0, E1, O1 */
         if constexpr (CLS == 0) {
             i0 = edge_idx(mid.E0, mid.lE0, mid.O0);
@@ -116,13 +116,17 @@ __device__ __forceinline__ void edge_rows(const SaoRaw (&raw)[10], const Store &
     }
 }
 
-/* one 8x8 block given its ten raw rows: not applied / kept (copy), band offset, or edge offset */
-template <bool BORDER, typename Store>
-__device__ __forceinline__ void block(const SaoRaw (&raw)[10], const Store &store, int x, int y0, int w, int h, const DbkSaoCtb &c, bool kept)
+/* one 8x8 block: not applied / kept (copy), band offset, or edge offset.  fetch(i) returns raw row i = image row y0 - 1 + i
+ * (i = 0 .. 9; rows 0 and 9 are asked for by the edge classes only) -- from registers, or from LDS as the rows are needed */
+template <bool BORDER, typename Fetch, typename Store>
+__device__ __forceinline__ void block(const Fetch &fetch, const Store &store, int x, int y0, int w, int h, const DbkSaoCtb &c, bool kept)
 {
     if (kept || c.type == 0 || c.type > 2) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) store(r, raw[r + 1].cx, raw[r + 1].cy);
+        for (int r = 0; r < 8; r++) {
+            const SaoRaw q = fetch(r + 1);
+            store(r, q.cx, q.cy);
+        }
         return;
     }
     auto b = [](int v) { return (uint32_t)(v + 128) & 0xffu; };
@@ -136,7 +140,7 @@ __device__ __forceinline__ void block(const SaoRaw (&raw)[10], const Store &stor
         };
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const SaoRow m = unpack<false>(raw[r + 1]);
+            const SaoRow m = unpack<false>(fetch(r + 1));
             store(r, band(m.E0) | (band(m.O0) << 8), band(m.E1) | (band(m.O1) << 8));
         }
         return;
@@ -144,10 +148,10 @@ __device__ __forceinline__ void block(const SaoRaw (&raw)[10], const Store &stor
     /* edge offset: index 0 -> SaoOffsetVal[1], 1 -> [2], 2 -> none, 3 -> [3], 4 -> [4] */
     const uint32_t tab_lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (b(0) << 16) | (b(c.offset[2]) << 24), tab_hi = b(c.offset[3]);
     const int cls = c.cls & 3;
-    if (cls == 0) edge_rows<0, BORDER>(raw, store, x, y0, w, h, tab_lo, tab_hi);
-    else if (cls == 1) edge_rows<1, BORDER>(raw, store, x, y0, w, h, tab_lo, tab_hi);
-    else if (cls == 2) edge_rows<2, BORDER>(raw, store, x, y0, w, h, tab_lo, tab_hi);
-    else edge_rows<3, BORDER>(raw, store, x, y0, w, h, tab_lo, tab_hi);
+    if (cls == 0) edge_rows<0, BORDER>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
+    else if (cls == 1) edge_rows<1, BORDER>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
+    else if (cls == 2) edge_rows<2, BORDER>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
+    else edge_rows<3, BORDER>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
 }
 
 } /* namespace sao8 */

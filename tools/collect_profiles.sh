@@ -57,6 +57,10 @@ python3 "$R/tools/clock_power_trace.py" > "$OUT/clock_power_filter_4k8.json" 2>/
 python3 "$R/tools/clock_power_trace.py" --variant copy > "$OUT/clock_power_copy_4k8.json" 2>/dev/null || true
 python3 "$R/tools/clock_power_trace.py" --width 7680 --height 4320 --bit-depth 10 --frames 32 > "$OUT/clock_power_8k10.json" 2>/dev/null || true
 python3 "$R/tools/bench_yuv420.py" --bit-depth 10 --frames 48 > "$OUT/bench_yuv420_10bit.json" 2>/dev/null || true
+python3 "$R/tools/bench_deblock_sao.py" > "$OUT/bench_deblock_sao.json" 2>/dev/null || true
+python3 "$R/tools/bench_deblock_sao.py" --mode h265 >> "$OUT/bench_deblock_sao.json" 2>/dev/null || true
+python3 "$R/tools/bench_deblock_sao.py" --frames 256 --steps 100 >> "$OUT/bench_deblock_sao.json" 2>/dev/null || true
+python3 "$R/tools/fused_profile.py" > "$OUT/fused_deblock_sao_profile.json" 2>/dev/null || true
 python3 "$R/tools/bench_yuv420.py" --bit-depth 10 --frames 48 --diag nofuse > "$OUT/bench_yuv420_10bit_nofuse.json" 2>/dev/null || true
 "$R/tools/ubench/valu_rate" > "$OUT/ubench_valu_rate.txt" 2>&1 || true
 "$R/tools/ubench/copy_bw" > "$OUT/ubench_copy_bw.txt" 2>&1 || true
