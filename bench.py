@@ -14,7 +14,8 @@ Scaling is weak: every rank filters its own F frames.
 
 After the headline measurement, rank 0 of a one-GPU run adds (each with its own bit-exactness spot check):
   extra_configs   the same kernel at 64 frames per launch (a decoder-sized batch), BASELINE config 4 as whole
-                  4:2:0 frames (Y + U + V) and config 5 (7680x4320 10-bit luma), with ms_per_step / frac / bytes;
+                  4:2:0 frames (Y + U + V), deblocking + SAO in one kernel against the two launches it replaces
+                  (SURVEY 8f rank 4) and config 5 (7680x4320 10-bit luma), with ms_per_step / frac / bytes;
   cpu_baseline    the reference's thread ladder (main.cu:36-83: 1, 2, 4, 6, 8 threads, plus all host cores):
                   >= 30 repetitions each, min and median, filter-only window (main.cu:41-43);
   reference_table the reference README's own line (README.md:19-24): 352x288 QP 35 Y+U+V, CPU 1T, CPU OpenMP,
@@ -288,6 +289,39 @@ def extra_configs(ctx, args, frames, batch, variant):
             "achieved_GBps": r["achieved"], "algorithmic_bytes": abytes, "steps": steps, "bit_exact_vs_oracle": ok}
         for b, _ in cb:
             b.free()
+
+    # (2b) SURVEY 8f rank 4: deblocking + SAO of the luma batch in ONE kernel against the two launches it replaces
+    if bd == 8:
+        from oracle import h265
+        Fs = min(F, 64)
+        rows, cols = (h + 63) // 64, (w + 63) // 64
+        prm = h265.random_sao_params(w, h, 6, seed=17, bit_depth=bd)
+        dp = ctx.alloc(prm.nbytes)
+        dp.upload(prm.view(np.uint8).ravel())
+        ps = batch.planes()
+        ps.n_frames = Fs
+        res = {}
+        for name, fused in (("one_kernel", _lib.FUSED_ON), ("two_launches", _lib.FUSED_OFF)):
+            for _ in range(max(settle, 50)):
+                ctx.deblock_sao_device(ps, qp, dp.ptr, prm.shape[1], 6, fused=fused)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ctx.deblock_sao_device(ps, qp, dp.ptr, prm.shape[1], 6, fused=fused)
+            ctx.synchronize()
+            res[name] = (time.perf_counter() - t0) / steps
+            want = h265.sao_plane(oracle.filter_plane(frames[Fs - 1], qp, threads=8), prm, 6)
+            res[name + "_ok"] = bool(np.array_equal(batch.download_frame(Fs - 1), want))
+        dp.free()
+        out["deblock_sao_fused"] = {
+            "workload": "%dx%d 8-bit luma, %d frames per call, deblocking (QP %d, default bS) + SAO (seeded per-CTB parameters), "
+                        "src -> dst, wall clock per call" % (w, h, Fs, qp),
+            "ms_per_step": res["one_kernel"] * 1e3, "ms_per_step_two_launches": res["two_launches"] * 1e3,
+            "luma_frames_per_s": Fs / res["one_kernel"], "speedup_over_two_launches": res["two_launches"] / res["one_kernel"],
+            "frac": 2 * Fs * w * h * sb / res["one_kernel"] / (HBM_PEAK_GBPS * 1e9),
+            "algorithmic_bytes": 2 * Fs * w * h * sb, "steps": steps,
+            "bit_exact_vs_oracle": res["one_kernel_ok"] and res["two_launches_ok"],
+            "parity": "the SAO stage is checked against this repository's own restatement of H.265 8.7.3 (unpinned)"}
 
     # (3) BASELINE config 5: 7680x4320 10-bit luma in 16-bit containers
     if not args.no_config5:
