@@ -2,7 +2,7 @@
 """Randomised soak of the HIP path against the oracles (run by hand on a GPU box; not collected by pytest):
    python tests/soak_gpu.py [--cases 400] [--seed 1]
 Every case draws a geometry, bit depth, plane kind, QP (scalar or map), bS arrays, frame count, in-place or not, and runs
-both kernels of the reference-exact mode and of the spec-exact mode, and every third case a whole 4:2:0 batch through
+both kernels of the reference-exact mode and of the spec-exact mode, 8-bit scalar-QP cases also through deblocking + SAO in one kernel and as two launches, and every third case a whole 4:2:0 batch through
 hevc_deblocking_filter_device_planes and the host-frame operator; any mismatch prints the case and exits non-zero."""
 import argparse, os, sys
 import numpy as np
@@ -95,6 +95,42 @@ def main():
                 if b.qp_map is not None:
                     b.qp_map.free()
                 b.free()
+        # 8-bit scalar-QP cases also through deblocking + SAO in one kernel (and as two launches), both filter modes
+        if bd == 8 and not use_map and not in_place:
+            ctb_log2 = int(rng.choice([3, 4, 5, 6]))
+            prm = np.stack([h265.random_sao_params(w, h, ctb_log2, seed=int(rng.randint(1, 1 << 30))) for _ in range(n)])
+            keep = (rng.randint(0, 5, (n, h // 8, w // 8)) == 0).astype(np.uint8)
+            dp, dk = ctx.alloc(prm.nbytes), ctx.alloc(keep.nbytes)
+            dp.upload(prm.view(np.uint8).ravel())
+            dk.upload(keep.ravel())
+            kw = dict(params_frame_stride=prm.shape[1] * prm.shape[2], keep_ptr=dk.ptr, keep_stride=w // 8, keep_frame_stride=(h // 8) * (w // 8))
+            b = deblock.DeviceBatch(ctx, w, h, n, is_chroma=chroma, per_frame_bs=False)
+            b.upload_all(frames)
+            b.set_bs(0, rvb, rhb)
+            want = [h265.sao_plane(want_ref[f], prm[f], ctb_log2, keep=keep[f]) for f in range(n)]
+            for fused in (_lib.FUSED_ON, _lib.FUSED_OFF):
+                ctx.deblock_sao_device(b.planes(), qp, dp.ptr, prm.shape[2], ctb_log2, fused=fused, **kw)
+                ctx.synchronize()
+                for f in range(n):
+                    if not np.array_equal(b.download_frame(f), want[f]):
+                        print("MISMATCH deblock+sao ref", fused, f, tag, ctb_log2)
+                        bad += 1
+            dv, dh = ctx.alloc(vb.size), ctx.alloc(hb.size)
+            dv.upload(vb)
+            dh.upload(hb)
+            p = b.planes()
+            p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
+            want = [h265.sao_plane(want_spec[f], prm[f], ctb_log2, keep=keep[f]) for f in range(n)]
+            for fused in (_lib.FUSED_ON, _lib.FUSED_OFF):
+                ctx.deblock_sao_h265_device(p, qp_s, dp.ptr, prm.shape[2], ctb_log2, c_idx=1 if chroma else 0, cb_qp_offset=cq, fused=fused, **offs, **kw)
+                ctx.synchronize()
+                for f in range(n):
+                    if not np.array_equal(b.download_frame(f), want[f]):
+                        print("MISMATCH deblock+sao spec", fused, f, tag, ctb_log2, offs, cq)
+                        bad += 1
+            for x in (dp, dk, dv, dh):
+                x.free()
+            b.free()
         # every third case also as a whole 4:2:0 frame batch: Y, U, V in one call (the fused launch where it applies, 8-bit and
         # 16-bit containers) and through the host-frame operator (small frames: no DMA; large: strips)
         if case % 3 == 0 and w % 16 == 0 and h % 16 == 0:
