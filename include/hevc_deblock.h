@@ -370,7 +370,9 @@ HEVCDBK_API int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_devic
  * (plus a one-sample rim) into LDS and applies SAO from there, so every sample is read from HBM once and written once and the
  * deblocked picture never exists in memory.  Other operands (16-bit containers, QP maps) run as two launches through a
  * scratch plane owned by the context.  `fused`: HEVCDBK_FUSED_AUTO picks, _OFF forces the two launches (same bytes; for
- * A/B runs), _ON returns HEVCDBK_ERR_UNSUPPORTED where the fused kernel does not apply.  Parity: the deblocking stage as for
+ * A/B runs), _ON returns HEVCDBK_ERR_UNSUPPORTED where the fused kernel does not apply.  The scratch plane of the two-launch
+ * form belongs to the context and is reused by the next such call: calls on one context are stream-ordered on ONE stream
+ * (like every entry point, a context serves one host thread at a time).  Parity: the deblocking stage as for
  * its own entry points; SAO against oracle/h265_oracle.c only ("parity unpinned").
  */
 #define HEVCDBK_FUSED_AUTO 0
