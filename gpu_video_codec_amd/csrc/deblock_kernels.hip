@@ -1151,7 +1151,7 @@ bool dbk_deblock_sao_supports(const DbkArgs &d, const DbkSaoArgs &s, int sample_
     if ((unsigned long long)s.pitch * (unsigned long long)s.plane_h >= (1ull << 31) || s.pitch % 4 != 0 || s.frame_stride % 4 != 0 ||
         ((uintptr_t)s.dst % 4) != 0)
         return false;
-    const unsigned long long tiles = (unsigned long long)((d.plane_w + kFusedTile - 1) / kFusedTile) * ((d.plane_h + kFusedTile - 1) / kFusedTile);
+    const unsigned long long tiles = (unsigned long long)((d.plane_w + kFusedTileW - 1) / kFusedTileW) * ((d.plane_h + kFusedTile - 1) / kFusedTile);
     return tiles * (unsigned long long)d.n_frames + 8 < (1ull << 31) && tiles * tiles < (1ull << 32) &&
            (tiles * d.n_frames + 8) * tiles < (1ull << 32); /* exact reciprocal divisions: dividend < 2^32 / divisor */
 }
@@ -1159,7 +1159,7 @@ bool dbk_deblock_sao_supports(const DbkArgs &d, const DbkSaoArgs &s, int sample_
 /* 1-D grid of the fused kernel, a multiple of 8 workgroups */
 static unsigned fused_grid(int plane_w, int plane_h, int n_frames, DbkFusedGrid &g)
 {
-    const unsigned long long tx = (plane_w + kFusedTile - 1) / kFusedTile, ty = (plane_h + kFusedTile - 1) / kFusedTile, tpf = tx * ty;
+    const unsigned long long tx = (plane_w + kFusedTileW - 1) / kFusedTileW, ty = (plane_h + kFusedTile - 1) / kFusedTile, tpf = tx * ty;
     g.tiles_x = (uint32_t)tx;
     g.tiles_per_frame = (uint32_t)tpf;
     g.total = (uint32_t)(tpf * n_frames);

@@ -366,7 +366,7 @@ HEVCDBK_API int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_devic
  * a decoder.  Operands as for hevc_deblocking_filter_device (reference-exact mode: `qp`, `tables`, the
  * planes' bS arrays) resp. hevc_deblocking_filter_h265_device (spec-exact mode: `c_idx`, `qp`, `h265_params`, the planes'
  * 4-sample-granular bS arrays) and for hevc_sao_filter_device (`params` ... `keep_frame_stride`, all DEVICE memory).
- * For 8-bit planes with a scalar QP both stages run in ONE kernel: a workgroup deblocks the offset blocks of a 128 x 128 tile
+ * For 8-bit planes with a scalar QP both stages run in ONE kernel: a workgroup deblocks the offset blocks of a 192 x 128 tile
  * (plus a one-sample rim) into LDS and applies SAO from there, so every sample is read from HBM once and written once and the
  * deblocked picture never exists in memory.  Other operands (16-bit containers, QP maps) run as two launches through a
  * scratch plane owned by the context.  `fused`: HEVCDBK_FUSED_AUTO picks, _OFF forces the two launches (same bytes; for

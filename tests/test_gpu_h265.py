@@ -251,9 +251,8 @@ def test_sao_on_device(ctx, h265):
 
 def test_deblock_sao_one_call(ctx, h265, oracle):
     """hevc_deblock_sao_device / hevc_deblock_sao_h265_device: deblocking followed by SAO, src -> dst, as ONE kernel (a
-    workgroup deblocks the offset blocks of a 128 x 128 tile into LDS and applies SAO from there) and as two launches through
-    the context's scratch plane: both equal the oracle chain SAO(deblock(x)).  Geometries around the tile edge (127 / 128 /
-    129 blocks would be 1016 / 1024 / 1032 samples), planes smaller than a tile, luma and chroma, CTB sizes 16 / 32 / 64, keep
+    workgroup deblocks the offset blocks of a 192 x 128 tile into LDS and applies SAO from there) and as two launches through
+    the context's scratch plane: both equal the oracle chain SAO(deblock(x)).  Geometries around tile edges, planes smaller than a tile, luma and chroma, CTB sizes 16 / 32 / 64, keep
     map, per-frame bS and parameters, pitched planes; 10 bit takes the two-launch form behind the same call and the fused
     selector refuses it."""
     from gpu_video_codec_amd import deblock, synth, _lib

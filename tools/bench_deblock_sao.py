@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Deblocking + SAO of F x 3840x2160 8-bit luma planes in HBM, src -> dst, in one call: the fused kernel
-(hevc_deblock_sao_device, one workgroup = one 128x128 tile through LDS) against the two launches it replaces
+(hevc_deblock_sao_device, one workgroup = one 192x128 tile through LDS) against the two launches it replaces
 (HEVCDBK_FUSED_OFF: deblocking into the context's scratch plane, then the SAO pass).  Seeded per-CTB SAO parameters (one
 third off / band / edge, or --types), wall clock over back-to-back calls after a settling period.  Diagnostic."""
 import argparse, json, os, sys, time
