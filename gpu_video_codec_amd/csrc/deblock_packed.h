@@ -43,6 +43,10 @@ DBK_HD pk splat(int v) { return pk{(short)v, (short)v}; }
 DBK_HD pk splat_u(int v) { const uint32_t x = (uint32_t)v & 0xffffu; return bits_pk(x | (x << 16)); }
 /* all-ones / all-zeros in both halves from a lane condition: one v_cndmask, no re-packing */
 DBK_HD pk mask_of(bool c) { return bits_pk(c ? 0xffffffffu : 0u); }
+/* 1 / 0 in both halves from a lane condition: the factor of a packed multiply-add that applies or drops a delta */
+DBK_HD pk one_of(bool c) { return bits_pk(c ? 0x00010001u : 0u); }
+/* a * b + c on three registers: v_pk_mad_i16 */
+DBK_HD pk mad_vvv(pk a, pk b, pk c) { return a * b + c; }
 
 DBK_HD pk pk_max(pk a, pk b)
 {
@@ -61,6 +65,17 @@ DBK_HD pk pk_min(pk a, pk b)
 #endif
 }
 DBK_HD pk pk_abs(pk a) { return pk_max(a, splat(0) - a); }
+/* max(a - b, 0) of non-negative fields: ONE v_pk_sub_u16 with the clamp bit (unsigned saturation) */
+DBK_HD pk sub_sat(pk a, pk b)
+{
+#if DBK_DEV
+    typedef unsigned short upk __attribute__((vector_size(4)));
+    return __builtin_bit_cast(pk, __builtin_elementwise_sub_sat(__builtin_bit_cast(upk, a), __builtin_bit_cast(upk, b)));
+#else
+    const unsigned short a0 = (unsigned short)a[0], a1 = (unsigned short)a[1], b0 = (unsigned short)b[0], b1 = (unsigned short)b[1];
+    return pk{(short)(a0 > b0 ? a0 - b0 : 0), (short)(a1 > b1 ? a1 - b1 : 0)};
+#endif
+}
 
 /*
  * Carry-free SWAR forms.  On gfx950 the packed v_pk_add/sub_u16 issue at 4 cycles per wave64 while a
@@ -174,8 +189,9 @@ struct Decision {
 
 DBK_HD Decision decide(const Taps &a, int beta, int tc)
 {
-    const pk dp = absdiff(uadd(a.p2, a.p0), uadd(a.p1, a.p1)); /* |p2 - 2p1 + p0| on lines 0 and 3 */
-    const pk dq = absdiff(uadd(a.q2, a.q0), uadd(a.q1, a.q1));
+    /* |p2 - 2p1 + p0| on lines 0 and 3: one add, one multiply-add, negate, max (four instead of five instructions) */
+    const pk tp = mad_k<-2>(a.p1, uadd(a.p2, a.p0)), tq = mad_k<-2>(a.q1, uadd(a.q2, a.q0));
+    const pk dp = pk_max(tp, splat(0) - tp), dq = pk_max(tq, splat(0) - tq);
     const pk dpq = uadd(dp, dq);
     Decision d;
     /* sum of the two halves in the low 16 bits: x + (x >> 16), compared as a 16-bit value */
@@ -212,15 +228,18 @@ DBK_HD pk shr_sum(pk x)
 
 /* strong filter (cpu.h:1152-1211), c = 2*tc.
  *
- * p' = clip(s, p - c, p + c) is evaluated as clip(s + c, p, p + 2c) - c: the "+ c" rides for free on the rounding
- * constants of the sums (s0 and s1 carry the shared p0+q0+2 term twice / once under >>3 / >>2, so that term takes
- * 2 + 4c; s2 gets the same constant once more), which removes the signed p - c of every tap and leaves max, min and
- * two carry-free 32-bit adds per output.  All fields stay non-negative and below 2^15 (8*max_v + 4 + 8c). */
+ * p' = clip(s, p - c, p + c) is evaluated as p + min(max((s + c) - p, 0), 2c) - c: the "+ c" rides for free on the rounding
+ * constants of the sums (s0 and s1 carry the shared p0+q0+2 term twice / once under >>3 / >>2, so that term takes 2 + 4c; s2
+ * gets the same constant once more); max(. - p, 0) is ONE saturating unsigned subtraction, the cap 2c and the final - c are
+ * wave-uniform operands, and p + x - c is one three-operand add on the packed register: both fields of p + x are >= c (x = 0
+ * only where s < p - c, i.e. p > c, because s >= 0), so no borrow crosses the field boundary.  Three instructions per output
+ * (round 1-2: max, add, min, sub).  All fields stay non-negative and below 2^15 (8*max_v + 4 + 8c; WIDE: below 2^16). */
 template <bool WIDE = false>
 DBK_HD void strong_pair(Taps &t, pk c)
 {
     const pk k = uaddc(uadd(uadd(c, c), uadd(c, c)), 0x00020002u); /* 2 + 4c */
     const pk c2 = uadd(c, c);
+    const uint32_t negc = 0u - pk_bits(c);
     const pk u2 = uadd(uadd(t.p0, t.q0), k);
     const pk tp = uadd(u2, t.p1);       /* p1+p0+q0+2 (+4c) */
     const pk tq = uadd(u2, t.q1);
@@ -233,12 +252,19 @@ DBK_HD void strong_pair(Taps &t, pk c)
     const pk s0q = shr_sum<WIDE, 3>(uadd(uadd(tq, bq), t.p1));
     const pk s1q = shr_sum<WIDE, 2>(bq);
     const pk s2q = shr_sum<WIDE, 3>(uadd(uadd(uadd(q32, q32), bq), k));
-    const pk np0 = usub(pk_min(pk_max(s0p, t.p0), uadd(t.p0, c2)), c);
-    const pk np1 = usub(pk_min(pk_max(s1p, t.p1), uadd(t.p1, c2)), c);
-    const pk np2 = usub(pk_min(pk_max(s2p, t.p2), uadd(t.p2, c2)), c);
-    const pk nq0 = usub(pk_min(pk_max(s0q, t.q0), uadd(t.q0, c2)), c);
-    const pk nq1 = usub(pk_min(pk_max(s1q, t.q1), uadd(t.q1, c2)), c);
-    const pk nq2 = usub(pk_min(pk_max(s2q, t.q2), uadd(t.q2, c2)), c);
+    /* hipcc splits p + x + negc into (p - c) + x, two instructions: the three-operand add is written out */
+    auto fin = [&](pk s, pk p) {
+        const pk x = pk_min(sub_sat(s, p), c2);
+#if DBK_DEV
+        uint32_t d;
+        asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(pk_bits(p)), "v"(pk_bits(x)), "s"(negc));
+        return bits_pk(d);
+#else
+        return bits_pk(pk_bits(p) + pk_bits(x) + negc);
+#endif
+    };
+    const pk np0 = fin(s0p, t.p0), np1 = fin(s1p, t.p1), np2 = fin(s2p, t.p2);
+    const pk nq0 = fin(s0q, t.q0), nq1 = fin(s1q, t.q1), nq2 = fin(s2q, t.q2);
     t.p0 = np0; t.p1 = np1; t.p2 = np2;
     t.q0 = nq0; t.q1 = nq1; t.q2 = nq2;
 }
@@ -274,7 +300,7 @@ DBK_HD pk normal_delta(const Taps &t)
 }
 
 /* normal filter (cpu.h:1251-1354) of one line pair given its delta, up to, but not including, the final Clip2 to
- * [0, max_v]; m5 / m6 = all-ones halves where cond5 / cond6 hold.  ALL_ON: the caller has established that
+ * [0, max_v]; m5 / m6 = 1 in both halves where cond5 / cond6 hold, else 0 (one_of).  ALL_ON: the caller has established that
  * |delta| < 10*tc (cpu.h:1254) holds in every line of every lane of the wave, so no per-line mask is needed */
 template <bool ALL_ON>
 DBK_HD void normal_apply(Taps &t, pk delta, const NormalK &k, pk m5, pk m6)
@@ -286,18 +312,19 @@ DBK_HD void normal_apply(Taps &t, pk delta, const NormalK &k, pk m5, pk m6)
     const pk xq = uaddc(uadd(t.q2, t.q0), 0x00010001u);
     const pk dp1 = pk_min(pk_max(mad_k<2>(D, mad_k<-2>(t.p1, xp)) >> 2, k.negc2), k.c2);
     const pk dq1 = pk_min(pk_max(mad_k<-2>(D, mad_k<-2>(t.q1, xq)) >> 2, k.negc2), k.c2);
+    /* m5 / m6 are 1 / 0 factors (one_of): p1 + dp1 * m5 is ONE multiply-add instead of a mask and an add */
     if constexpr (ALL_ON) {
         t.p0 = t.p0 + D;
         t.q0 = t.q0 - D;
-        t.p1 = t.p1 + (dp1 & m5);
-        t.q1 = t.q1 + (dq1 & m6);
+        t.p1 = mad_vvv(dp1, m5, t.p1);
+        t.q1 = mad_vvv(dq1, m6, t.q1);
     } else {
         const pk on = (pk_abs(delta) - k.lim) >> 15; /* all ones where |delta| < 10*tc (cpu.h:1254) */
         const pk Dm = D & on;
         t.p0 = t.p0 + Dm;
         t.q0 = t.q0 - Dm;
-        t.p1 = t.p1 + (dp1 & on & m5);
-        t.q1 = t.q1 + (dq1 & on & m6);
+        t.p1 = mad_vvv(dp1 & on, m5, t.p1);
+        t.q1 = mad_vvv(dq1 & on, m6, t.q1);
     }
 }
 
@@ -368,7 +395,7 @@ DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc, int max_v = 255, int 
         strong_pair<WIDE>(a, c);
         strong_pair<WIDE>(b, c);
     } else if (ablate != 2) {
-        normal_pairs<WIDE>(a, b, tc, mask_of(d.cond5), mask_of(d.cond6), max_v);
+        normal_pairs<WIDE>(a, b, tc, one_of(d.cond5), one_of(d.cond6), max_v);
     }
     return true;
 }
