@@ -185,6 +185,7 @@ struct Decision {
     bool filter; /* cond1 */
     bool strong; /* cond2 && cond3 && cond4 */
     bool cond5, cond6;
+    pk tp, tq;   /* p2 - 2p1 + p0 and q2 - 2q1 + q0 of pair A (signed): the normal filter's p1 / q1 terms start from them */
 };
 
 DBK_HD Decision decide(const Taps &a, int beta, int tc)
@@ -192,8 +193,10 @@ DBK_HD Decision decide(const Taps &a, int beta, int tc)
     /* |p2 - 2p1 + p0| on lines 0 and 3: one add, one multiply-add, negate, max (four instead of five instructions) */
     const pk tp = mad_k<-2>(a.p1, uadd(a.p2, a.p0)), tq = mad_k<-2>(a.q1, uadd(a.q2, a.q0));
     const pk dp = pk_max(tp, splat(0) - tp), dq = pk_max(tq, splat(0) - tq);
-    const pk dpq = uadd(dp, dq);
     Decision d;
+    d.tp = tp;
+    d.tq = tq;
+    const pk dpq = uadd(dp, dq);
     /* sum of the two halves in the low 16 bits: x + (x >> 16), compared as a 16-bit value */
     d.filter = lohi_sum(dpq) < (unsigned)beta;                  /* cpu.h:1086-1087 */
     const pk e = uadd(absdiff(a.p3, a.p0), absdiff(a.q0, a.q3)); /* cpu.h:1104-1105 */
@@ -302,16 +305,23 @@ DBK_HD pk normal_delta(const Taps &t)
 /* normal filter (cpu.h:1251-1354) of one line pair given its delta, up to, but not including, the final Clip2 to
  * [0, max_v]; m5 / m6 = 1 in both halves where cond5 / cond6 hold, else 0 (one_of).  ALL_ON: the caller has established that
  * |delta| < 10*tc (cpu.h:1254) holds in every line of every lane of the wave, so no per-line mask is needed */
-template <bool ALL_ON>
-DBK_HD void normal_apply(Taps &t, pk delta, const NormalK &k, pk m5, pk m6)
+template <bool ALL_ON, bool HAVE_T = false>
+DBK_HD void normal_apply(Taps &t, pk delta, const NormalK &k, pk m5, pk m6, pk tp = pk{0, 0}, pk tq = pk{0, 0})
 {
     const pk D = pk_min(pk_max(delta, k.negc), k.c);
     /* (((p2+p0+1)>>1) - p1 + D) >> 1  ==  (p2 + p0 + 1 - 2*p1 + 2*D) >> 2   (floor of a floor: the dropped
-     * bit of the inner shift is worth 1/4 and cannot carry across an integer) */
-    const pk xp = uaddc(uadd(t.p2, t.p0), 0x00010001u);
-    const pk xq = uaddc(uadd(t.q2, t.q0), 0x00010001u);
-    const pk dp1 = pk_min(pk_max(mad_k<2>(D, mad_k<-2>(t.p1, xp)) >> 2, k.negc2), k.c2);
-    const pk dq1 = pk_min(pk_max(mad_k<-2>(D, mad_k<-2>(t.q1, xq)) >> 2, k.negc2), k.c2);
+     * bit of the inner shift is worth 1/4 and cannot carry across an integer).  HAVE_T: p2 + p0 - 2*p1 (and the Q twin) of
+     * this pair is already there from the decisions (pair A) */
+    pk ip, iq;
+    if constexpr (HAVE_T) {
+        ip = tp + splat(1);
+        iq = tq + splat(1);
+    } else {
+        ip = mad_k<-2>(t.p1, uaddc(uadd(t.p2, t.p0), 0x00010001u));
+        iq = mad_k<-2>(t.q1, uaddc(uadd(t.q2, t.q0), 0x00010001u));
+    }
+    const pk dp1 = pk_min(pk_max(mad_k<2>(D, ip) >> 2, k.negc2), k.c2);
+    const pk dq1 = pk_min(pk_max(mad_k<-2>(D, iq) >> 2, k.negc2), k.c2);
     /* m5 / m6 are 1 / 0 factors (one_of): p1 + dp1 * m5 is ONE multiply-add instead of a mask and an add */
     if constexpr (ALL_ON) {
         t.p0 = t.p0 + D;
@@ -356,18 +366,20 @@ DBK_HD bool any_lane(bool v)
  * min/max instructions run only in waves where some lane needs them.  Likewise the |delta| < 10*tc switch of a line
  * (cpu.h:1254): a line fails it only across a real picture edge, so the per-line masks are built only in waves where
  * some lane has such a line. */
-template <bool WIDE = false>
-DBK_HD void normal_pairs(Taps &a, Taps &b, int tc, pk m5, pk m6, int max_v)
+template <bool WIDE = false, bool HAVE_T = false>
+DBK_HD void normal_pairs(Taps &a, Taps &b, int tc, pk m5, pk m6, int max_v, pk tp = pk{0, 0}, pk tq = pk{0, 0})
 {
     const NormalK k = normal_k(tc);
     {
         const pk da = normal_delta<WIDE>(a);
-        if (any_lane(tc > 0 ? normal_some_line_off(da, k) : true)) normal_apply<false>(a, da, k, m5, m6);
-        else normal_apply<true>(a, da, k, m5, m6);
+        /* the wave-uniform tc == 0 case joins the ballot as a scalar OR (selecting between a scalar `true` and the lane
+         * condition would make the compiler materialise the lane mask in a VGPR and compare it again) */
+        if (tc <= 0 || any_lane(normal_some_line_off(da, k))) normal_apply<false, HAVE_T>(a, da, k, m5, m6, tp, tq);
+        else normal_apply<true, HAVE_T>(a, da, k, m5, m6, tp, tq);
     }
     {
         const pk db = normal_delta<WIDE>(b);
-        if (any_lane(tc > 0 ? normal_some_line_off(db, k) : true)) normal_apply<false>(b, db, k, m5, m6);
+        if (tc <= 0 || any_lane(normal_some_line_off(db, k))) normal_apply<false>(b, db, k, m5, m6);
         else normal_apply<true>(b, db, k, m5, m6);
     }
     const uint32_t over = (pk_bits(a.p0) | pk_bits(a.q0) | pk_bits(a.p1) | pk_bits(a.q1) |
@@ -395,7 +407,7 @@ DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc, int max_v = 255, int 
         strong_pair<WIDE>(a, c);
         strong_pair<WIDE>(b, c);
     } else if (ablate != 2) {
-        normal_pairs<WIDE>(a, b, tc, one_of(d.cond5), one_of(d.cond6), max_v);
+        normal_pairs<WIDE, true>(a, b, tc, one_of(d.cond5), one_of(d.cond6), max_v, d.tp, d.tq);
     }
     return true;
 }
