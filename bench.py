@@ -12,6 +12,14 @@ processes, never an exec).  Frames shard frame-parallel with NO data-path collec
 torch.distributed (gloo) is used only for the barrier and the max-over-ranks of the elapsed time.
 Scaling is weak: every rank filters its own F frames.
 
+Timing discipline: the clock / power sampler and everything else on the host side is set up BEFORE the
+first launch; settle, warm-up and timed launches then go out as ONE uninterrupted stream (hevcdbk_device_replay): settling
+is by time (until the trailing 32 launches average within 0.5 % of the 32 before them, at least --settle-min-ms, at most
+--settle-max-ms), the front bracket of the timed window is the host observing the end of the last warm-up launch while the
+K timed launches are already queued behind it, the back bracket one stream synchronisation (the reference's window:
+kernels + sync, gpu.cu:1266-1291).  ms_per_step = that wall clock / K.  With N > 1 ranks the ranks settle, meet in a
+barrier, and every rank then runs [100 ms re-settle][warm-up][K timed] uninterrupted; value uses the MAX over ranks.
+
 After the headline measurement, rank 0 of a one-GPU run adds (each with its own bit-exactness spot check):
   extra_configs   the same kernel at 64 frames per launch (a decoder-sized batch), BASELINE config 4 as whole
                   4:2:0 frames (Y + U + V), deblocking + SAO in one kernel against the two launches it replaces
@@ -182,7 +190,6 @@ def live_traffic(w, h, F, bd, timeout_s=240):
     WRITE_SIZE, each alone, on the diagnostic copy variant for the calibration and on the product kernel) as child
     processes of a parent that has not touched the GPU yet.  None if rocprofv3 is missing or a pass fails."""
     import shutil
-    import subprocess
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
@@ -190,17 +197,60 @@ def live_traffic(w, h, F, bd, timeout_s=240):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "hbm_traffic.py"), "--tag", "live", "--frames", str(F), "--width", str(w),
            "--height", str(h), "--bit-depth", str(bd), "--outdir", out, "--no-profiles-copy"]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
-        if r.returncode != 0:
+        out_txt, _err, rc = run_group(cmd, timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        if rc != 0:
             return None
         with open(os.path.join(out, "live_hbm_traffic.json")) as fh:
             t = json.load(fh)
         return (t["hbm_bytes_per_launch"], "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                 "calibrated on the copy variant (read x%.3f, write x%.3f)" % (t["calibration"]["read_corr"], t["calibration"]["write_corr"]))
-    except (OSError, ValueError, KeyError, subprocess.TimeoutExpired):
+    except (OSError, ValueError, KeyError):
         return None
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+def run_group(cmd, timeout_s, cwd=None, env=None):
+    """Run a child in its OWN process group; on timeout the whole group is killed (a child that started rocprofv3 or
+    further python processes must not leave grandchildren holding the GPU).  Returns (stdout, stderr, returncode);
+    returncode is None after a timeout."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=cwd, env=env, start_new_session=True)
+    try:
+        o, e = p.communicate(timeout=timeout_s)
+        return o, e, p.returncode
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+            try:
+                p.communicate(timeout=10)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.communicate()
+        except ProcessLookupError:
+            pass
+        return "", "timeout", None
+
+
+def copy_floor(args):
+    """The memory floor of the kernel's own access pattern, measured in THIS invocation: a child process runs this script with
+    --variant copy (libhevcdbk_diag.so: the packed kernel's loads and stores with nothing in between) on the same workload
+    BEFORE this process touches the GPU.  None when the diagnostic library is missing or the child fails."""
+    if not os.path.exists(_lib.DIAG_LIB_PATH):
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--variant", "copy", "--steps", str(max(args.steps, 60)), "--warmup", str(args.warmup),
+           "--frames", str(args.frames), "--width", str(args.width), "--height", str(args.height), "--bit-depth", str(args.bit_depth),
+           "--qp", str(args.qp), "--settle-min-ms", str(args.settle_min_ms), "--settle-max-ms", str(args.settle_max_ms),
+           "--no-extra", "--no-e2e", "--no-cpu-baseline", "--traffic", "none", "--copy-floor", "off", "--no-telemetry"]
+    o, _e, rc = run_group(cmd, 300)
+    if rc != 0 or not o.strip():
+        return None
+    try:
+        r = json.loads(o.strip().splitlines()[-1])["roofline"]
+        return {"copy_floor_ms": r["kernel_avg_ms"], "copy_floor_p50_ms": r["kernel_ms_p50"], "copy_floor_frac": r["frac"]}
+    except (ValueError, KeyError):
+        return None
 
 
 def measured_traffic(w, h, F, bd):
@@ -232,36 +282,69 @@ def host_threads():
 
 
 def roofline_of(kernel_ms, abytes):
+    kernel_ms = np.asarray(kernel_ms, np.float64)
     kavg_ms = float(np.mean(kernel_ms))
     achieved = abytes / (kavg_ms * 1e-3) / 1e9
+    p10, p50, p90 = (float(x) for x in np.percentile(kernel_ms, [10, 50, 90]))
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "kernel_avg_ms": kavg_ms, "kernel_min_ms": float(np.min(kernel_ms)), "algorithmic_bytes_per_launch": abytes}
+            "kernel_avg_ms": kavg_ms, "kernel_min_ms": float(np.min(kernel_ms)), "kernel_ms_p10": p10, "kernel_ms_p50": p50,
+            "kernel_ms_p90": p90, "first5_avg_ms": float(np.mean(kernel_ms[:5])), "last5_avg_ms": float(np.mean(kernel_ms[-5:])),
+            "algorithmic_bytes_per_launch": abytes}
+
+
+def settled_run(ctx, planes_list, qp, steps, variant, args, warmup=3):
+    """One uninterrupted [settle by time][warm-up][timed] stream on ctx; (kernel ms of the timed launches, replay info)."""
+    return ctx.replay(planes_list, qp, steps, warmup=warmup, settle_min_ms=args.settle_min_ms, settle_max_ms=args.settle_max_ms,
+                      variant=variant)
 
 
 def extra_configs(ctx, args, frames, batch, variant):
-    """Measured after the headline, same settle / warm-up discipline, fewer steps; each with a spot check against the
-    oracle.  Never `value`."""
+    """Measured after the headline with the same discipline (one uninterrupted settle-by-time + warm-up + timed stream per
+    figure), fewer steps; each with a spot check against the oracle.  Never `value`."""
     from oracle import oracle
     out = {}
     w, h, F, bd, qp = args.width, args.height, args.frames, args.bit_depth, args.qp
     sb = 1 if bd == 8 else 2
-    settle, steps = max(args.settle // 2, 10), max(min(args.steps, 60), 10)
+    steps = max(min(args.steps, 60), 20)
+
+    def line(ms, info, abytes, extra):
+        r = roofline_of(ms, abytes)
+        d = {"ms_per_step": r["kernel_avg_ms"], "kernel_ms_p10": r["kernel_ms_p10"], "kernel_ms_p50": r["kernel_ms_p50"],
+             "kernel_ms_p90": r["kernel_ms_p90"], "frac": r["frac"], "achieved_GBps": r["achieved"], "algorithmic_bytes": abytes,
+             "steps": len(ms), "settle_ms": info["settle_ms"], "settle_launches": info["settle_launches"], "settled": bool(info["settled"])}
+        d.update(extra)
+        return d
+
+    def wall_settled(call, steps_, min_ms=None, max_ms=None):
+        """entries without per-launch events: the same settle rule on blocks of 16 calls timed by the host (a block ends in
+        a synchronisation, so this is wall clock per call including the launch gaps), then `steps_` timed calls"""
+        min_ms = args.settle_min_ms if min_ms is None else min_ms
+        max_ms = args.settle_max_ms if max_ms is None else max_ms
+        t_first, hist, n = time.perf_counter(), [], 0
+        while max_ms > 0:
+            a = time.perf_counter()
+            for _ in range(16):
+                call()
+            ctx.synchronize()
+            hist.append((time.perf_counter() - a) / 16)
+            n += 16
+            el = (time.perf_counter() - t_first) * 1e3
+            if el >= max_ms or (el >= min_ms and len(hist) >= 4 and abs(sum(hist[-2:]) - sum(hist[-4:-2])) <= 0.005 * sum(hist[-4:-2])):
+                break
+        a = time.perf_counter()
+        for _ in range(steps_):
+            call()
+        ctx.synchronize()
+        return (time.perf_counter() - a) / steps_, {"settle_ms": (a - t_first) * 1e3, "settle_launches": n}
 
     # (1) the headline kernel at a decoder-sized batch: 64 frames per launch
     if F > 64:
         p = batch.planes()
         p.n_frames = 64
-        # the same settling TIME as the headline's 100 launches of 256 frames (the clock governor works in milliseconds, not in
-        # launches): four times as many launches of a quarter of the work
-        settle64, steps64 = 4 * args.settle, 4 * steps
-        ctx.run_timed([p], qp, max(settle64, 1), variant=variant)
-        ms = ctx.run_timed([p], qp, steps64, variant=variant)
-        r = roofline_of(ms, algorithmic_bytes_per_frame(w, h, sb) * 64)
-        out["luma_64_frames_per_launch"] = {
-            "workload": "%dx%d %d-bit luma, 64 frames per launch (same kernel, decoder-sized batch)" % (w, h, bd),
-            "ms_per_step": r["kernel_avg_ms"], "luma_frames_per_s": 64 / (r["kernel_avg_ms"] * 1e-3), "frac": r["frac"],
-            "achieved_GBps": r["achieved"], "algorithmic_bytes": r["algorithmic_bytes_per_launch"], "steps": steps64,
-            "settle_launches": settle64}
+        ms, info = settled_run(ctx, [p], qp, 4 * steps, variant, args)
+        out["luma_64_frames_per_launch"] = line(ms, info, algorithmic_bytes_per_frame(w, h, sb) * 64, {
+            "workload": "%dx%d %d-bit luma, 64 frames per launch (same kernel, decoder-sized batch)" % (w, h, bd)})
+        out["luma_64_frames_per_launch"]["luma_frames_per_s"] = 64 / (out["luma_64_frames_per_launch"]["ms_per_step"] * 1e-3)
 
     # (2) BASELINE config 4 as whole 4:2:0 frames: Y + U + V of every frame per step
     if bd == 8:
@@ -276,77 +359,127 @@ def extra_configs(ctx, args, frames, batch, variant):
         py = batch.planes()
         py.n_frames = Fc
         pl = [py, cb[0][0].planes(), cb[1][0].planes()]
-        ctx.run_timed(pl, qp, settle, variant=variant)
-        ms = ctx.run_timed(pl, qp, steps, variant=variant)
+        ms, info = settled_run(ctx, pl, qp, steps, variant, args)
         abytes = Fc * (algorithmic_bytes_per_frame(w, h, sb) + 2 * algorithmic_bytes_per_frame(cw, ch, sb))
-        r = roofline_of(ms, abytes)
         ok = bool(np.array_equal(batch.download_frame(Fc - 1), oracle.filter_plane(frames[Fc - 1], qp, threads=8)))
         for b, src in cb:
             ok &= bool(np.array_equal(b.download_frame(1), oracle.filter_plane(src[1], qp, is_chroma=True)))
-        out["config4_yuv420"] = {
+        out["config4_yuv420"] = line(ms, info, abytes, {
             "workload": "%dx%d 8-bit 4:2:0 (Y+U+V), %d frames per step, QP %d, default bS, device-resident" % (w, h, Fc, qp),
-            "ms_per_step": r["kernel_avg_ms"], "yuv420_frames_per_s": Fc / (r["kernel_avg_ms"] * 1e-3), "frac": r["frac"],
-            "achieved_GBps": r["achieved"], "algorithmic_bytes": abytes, "steps": steps, "bit_exact_vs_oracle": ok}
+            "bit_exact_vs_oracle": ok})
+        out["config4_yuv420"]["yuv420_frames_per_s"] = Fc / (out["config4_yuv420"]["ms_per_step"] * 1e-3)
+
+        # (2a) SURVEY 8f rank 4 on whole 4:2:0 frames: deblocking + SAO of Y, U and V
+        out.update(extra_deblock_sao(ctx, args, frames, batch, cb, steps, wall_settled))
         for b, _ in cb:
             b.free()
 
-    # (2b) SURVEY 8f rank 4: deblocking + SAO of the luma batch in ONE kernel against the two launches it replaces
+    # (2c) the SAO pass alone and the spec-exact deblocking kernel on 64 luma frames (both parity-unpinned stages)
     if bd == 8:
-        from oracle import h265
-        Fs = min(F, 64)
-        rows, cols = (h + 63) // 64, (w + 63) // 64
-        prm = h265.random_sao_params(w, h, 6, seed=17, bit_depth=bd)
-        dp = ctx.alloc(prm.nbytes)
-        dp.upload(prm.view(np.uint8).ravel())
-        ps = batch.planes()
-        ps.n_frames = Fs
-        res = {}
-        for name, fused in (("one_kernel", _lib.FUSED_ON), ("two_launches", _lib.FUSED_OFF)):
-            for _ in range(max(settle, 50)):
-                ctx.deblock_sao_device(ps, qp, dp.ptr, prm.shape[1], 6, fused=fused)
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                ctx.deblock_sao_device(ps, qp, dp.ptr, prm.shape[1], 6, fused=fused)
-            ctx.synchronize()
-            res[name] = (time.perf_counter() - t0) / steps
-            want = h265.sao_plane(oracle.filter_plane(frames[Fs - 1], qp, threads=8), prm, 6)
-            res[name + "_ok"] = bool(np.array_equal(batch.download_frame(Fs - 1), want))
-        dp.free()
-        out["deblock_sao_fused"] = {
-            "workload": "%dx%d 8-bit luma, %d frames per call, deblocking (QP %d, default bS) + SAO (seeded per-CTB parameters), "
-                        "src -> dst, wall clock per call" % (w, h, Fs, qp),
-            "ms_per_step": res["one_kernel"] * 1e3, "ms_per_step_two_launches": res["two_launches"] * 1e3,
-            "luma_frames_per_s": Fs / res["one_kernel"], "speedup_over_two_launches": res["two_launches"] / res["one_kernel"],
-            "frac": 2 * Fs * w * h * sb / res["one_kernel"] / (HBM_PEAK_GBPS * 1e9),
-            "algorithmic_bytes": 2 * Fs * w * h * sb, "steps": steps,
-            "bit_exact_vs_oracle": res["one_kernel_ok"] and res["two_launches_ok"],
-            "parity": "the SAO stage is checked against this repository's own restatement of H.265 8.7.3 (unpinned)"}
+        out.update(extra_h265_stages(ctx, args, frames, batch, steps, wall_settled))
 
     # (3) BASELINE config 5: 7680x4320 10-bit luma in 16-bit containers
     if not args.no_config5:
         w5, h5, bd5 = 7680, 4320, 10
-        # the frame pool of the headline batch serves this geometry too (a decoder's pool outlives a sequence): device memory
-        # obtained later in a process is often placed worse -- identical launches measured 0.71-0.79 ms from allocation to
-        # allocation at this size -- and the pool is the process's first, best-placed allocation
+        # two figures: (a) in the frame pool of the headline batch (a decoder's pool outlives a sequence; the process's
+        # first, best-placed allocation), (b) in a pool allocated now, the way a decoder that allocates per sequence gets
+        # it -- device memory obtained later in a process is often placed worse (identical launches measured
+        # 0.71-0.79 ms from allocation to allocation at this size), so both are on the record
         F5 = max(1, min(32, batch.src.nbytes // (w5 * h5 * 2)))
         f5 = make_frames(w5, h5, F5, bd5, seed=5, n_base=2)
-        b5 = deblock.DeviceBatch(ctx, w5, h5, F5, bit_depth=bd5, storage=(batch.src, batch.dst))
-        b5.upload_all(f5)
-        p5 = b5.planes()
-        ctx.run_timed([p5], qp, max(settle, 100), variant=variant)
-        ms = ctx.run_timed([p5], qp, max(steps, 100), variant=variant)
         abytes = F5 * algorithmic_bytes_per_frame(w5, h5, 2)
-        r = roofline_of(ms, abytes)
-        ok = bool(np.array_equal(b5.download_frame(F5 - 1), oracle.filter_plane(f5[F5 - 1], qp, bit_depth=bd5, threads=8)))
-        out["config5_8k_10bit"] = {
-            "workload": "%dx%d %d-bit luma (16-bit containers), %d frames per launch, QP %d, default bS" % (w5, h5, bd5, F5, qp),
-            "ms_per_step": r["kernel_avg_ms"], "luma_frames_per_s": F5 / (r["kernel_avg_ms"] * 1e-3), "frac": r["frac"],
-            "achieved_GBps": r["achieved"], "algorithmic_bytes": abytes, "steps": max(steps, 100), "bit_exact_vs_oracle": ok,
-            "device_memory": "the headline batch's frame pool, reused",
-            "parity": "unpinned beyond 8 bit (the reference is 8-bit only, SURVEY 8c): checked against the CPU restatement"}
-        b5.free()
+        want5 = oracle.filter_plane(f5[F5 - 1], qp, bit_depth=bd5, threads=8)
+        for key, storage, memo in (("config5_8k_10bit", (batch.src, batch.dst), "the headline batch's frame pool, reused"),
+                                   ("config5_8k_10bit_fresh_pool", None, "a pool allocated for this figure")):
+            b5 = deblock.DeviceBatch(ctx, w5, h5, F5, bit_depth=bd5, storage=storage)
+            b5.upload_all(f5)
+            ms, info = settled_run(ctx, [b5.planes()], qp, max(steps, 100), variant, args)
+            ok = bool(np.array_equal(b5.download_frame(F5 - 1), want5))
+            out[key] = line(ms, info, abytes, {
+                "workload": "%dx%d %d-bit luma (16-bit containers), %d frames per launch, QP %d, default bS" % (w5, h5, bd5, F5, qp),
+                "bit_exact_vs_oracle": ok, "device_memory": memo,
+                "parity": "unpinned beyond 8 bit (the reference is 8-bit only, SURVEY 8c): checked against the CPU restatement"})
+            out[key]["luma_frames_per_s"] = F5 / (out[key]["ms_per_step"] * 1e-3)
+            b5.free()
         del f5
+    return out
+
+
+def extra_deblock_sao(ctx, args, frames, batch, cb, steps, wall_settled):
+    """deblocking + SAO in ONE kernel against the two launches it replaces -- on 64 luma
+    frames, and on whole 4:2:0 frames (Y, U, V: three calls, or one where the library fuses the planes)."""
+    from oracle import oracle, h265
+    out = {}
+    w, h, F, bd, qp = args.width, args.height, args.frames, args.bit_depth, args.qp
+    sb = 1
+    Fs = min(F, 64)
+    prm = h265.random_sao_params(w, h, 6, seed=17, bit_depth=bd)
+    dp = ctx.alloc(prm.nbytes)
+    dp.upload(prm.view(np.uint8).ravel())
+    ps = batch.planes()
+    ps.n_frames = Fs
+    res = {}
+    for name, fused in (("one_kernel", _lib.FUSED_ON), ("two_launches", _lib.FUSED_OFF)):
+        res[name], res[name + "_info"] = wall_settled(lambda: ctx.deblock_sao_device(ps, qp, dp.ptr, prm.shape[1], 6, fused=fused), steps)
+        want = h265.sao_plane(oracle.filter_plane(frames[Fs - 1], qp, threads=8), prm, 6)
+        res[name + "_ok"] = bool(np.array_equal(batch.download_frame(Fs - 1), want))
+    out["deblock_sao_fused"] = {
+        "workload": "%dx%d 8-bit luma, %d frames per call, deblocking (QP %d, default bS) + SAO (seeded per-CTB parameters), "
+                    "src -> dst, wall clock per call" % (w, h, Fs, qp),
+        "ms_per_step": res["one_kernel"] * 1e3, "ms_per_step_two_launches": res["two_launches"] * 1e3,
+        "luma_frames_per_s": Fs / res["one_kernel"], "speedup_over_two_launches": res["two_launches"] / res["one_kernel"],
+        "frac": 2 * Fs * w * h * sb / res["one_kernel"] / (HBM_PEAK_GBPS * 1e9),
+        "algorithmic_bytes": 2 * Fs * w * h * sb, "steps": steps, "settle_ms": res["one_kernel_info"]["settle_ms"],
+        "bit_exact_vs_oracle": res["one_kernel_ok"] and res["two_launches_ok"],
+        "parity": "the SAO stage is checked against this repository's own restatement of H.265 8.7.3 (unpinned)"}
+    dp.free()
+    return out
+
+
+def extra_h265_stages(ctx, args, frames, batch, steps, wall_settled):
+    """The SAO pass alone (`sao_64`) and the spec-exact deblocking kernel (`h265_luma_64`: bS 2 on every interior edge) on 64
+    frames of the luma batch; both stages are parity-unpinned (checked against this repository's own restatements)."""
+    from oracle import h265
+    out = {}
+    w, h, F, bd, qp = args.width, args.height, args.frames, args.bit_depth, args.qp
+    Fs = min(F, 64)
+    ps = batch.planes()
+    ps.n_frames = Fs
+    # SAO: one third of the CTBs each off / band / edge
+    prm = h265.random_sao_params(w, h, 6, seed=17, bit_depth=bd)
+    dp = ctx.alloc(prm.nbytes)
+    dp.upload(prm.view(np.uint8).ravel())
+    dt, info = wall_settled(lambda: ctx.sao_device(ps, dp.ptr, prm.shape[1], 6), 4 * steps)
+    ok = bool(np.array_equal(batch.download_frame(Fs - 1), h265.sao_plane(frames[Fs - 1], prm, 6)))
+    nbytes = 2 * Fs * w * h
+    out["sao_64"] = {"workload": "SAO pass (H.265 8.7.3) on %dx%d 8-bit luma, %d frames per launch, seeded per-CTB parameters, src -> dst, "
+                                 "wall clock per launch" % (w, h, Fs),
+                     "ms_per_step": dt * 1e3, "frac": nbytes / dt / (HBM_PEAK_GBPS * 1e9), "achieved_GBps": nbytes / dt * 1e-9,
+                     "algorithmic_bytes": nbytes, "steps": 4 * steps, "settle_ms": info["settle_ms"], "bit_exact_vs_oracle": ok,
+                     "parity": "unpinned: checked against this repository's own restatement of H.265 8.7.3"}
+    dp.free()
+    # spec-exact deblocking: bS 2 on every interior edge (4-sample granular arrays, shared by all frames)
+    vb = np.zeros((h // 4, w // 8 + 1), np.uint8)
+    vb[:, 1:w // 8] = 2
+    hb = np.zeros((h // 8 + 1, w // 4), np.uint8)
+    hb[1:h // 8, :] = 2
+    dv, dh = ctx.alloc(vb.size), ctx.alloc(hb.size)
+    dv.upload(vb)
+    dh.upload(hb)
+    ph = batch.planes()
+    ph.n_frames = Fs
+    ph.vert_bs, ph.hor_bs, ph.vert_bs_stride, ph.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
+    dt, info = wall_settled(lambda: ctx.filter_device_h265(ph, qp, variant=_lib.KERNEL_PACKED), 4 * steps)
+    want = h265.filter_plane(frames[Fs - 1], qp, vb, hb)
+    ok = bool(np.array_equal(batch.download_frame(Fs - 1), want))
+    nbytes = Fs * (2 * w * h + vb.size + hb.size)
+    out["h265_luma_64"] = {"workload": "spec-exact deblocking (H.265 8.7.2) of %dx%d 8-bit luma, %d frames per launch, QP %d, bS 2 on every "
+                                       "interior edge, packed kernel, src -> dst, wall clock per launch" % (w, h, Fs, qp),
+                           "ms_per_step": dt * 1e3, "frac": nbytes / dt / (HBM_PEAK_GBPS * 1e9), "achieved_GBps": nbytes / dt * 1e-9,
+                           "algorithmic_bytes": nbytes, "steps": 4 * steps, "settle_ms": info["settle_ms"], "bit_exact_vs_oracle": ok,
+                           "parity": "unpinned: checked against this repository's own restatement of H.265 8.7.2"}
+    dv.free()
+    dh.free()
     return out
 
 
@@ -355,10 +488,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--settle", type=int, default=100,
-                    help="untimed launches before the warm-up steps: under this VALU-heavy kernel the clock governor "
-                         "dips for launches ~6-60 and then recovers (profiles/r01/clock_trace_*.txt); 100 launches "
-                         "(~25 ms) put the timed region in the steady state instead of in that transient")
+    ap.add_argument("--settle-min-ms", type=float, default=150.0,
+                    help="settle phase: launches go out, untimed, until the trailing 32 average within 0.5 %% of the 32 before them, "
+                         "for at least this long (the card idles at a few hundred MHz and takes tens of milliseconds under load to "
+                         "reach the clock it then holds at the power cap, profiles/r02/clock_trace_packed_4k8.txt)")
+    ap.add_argument("--settle-max-ms", type=float, default=2000.0, help="cap of the settle phase; 0 = no settling")
     ap.add_argument("--frames", type=int, default=256,
                     help="frames per GPU per step (one launch filters the whole batch; 256 x 4K 8-bit = 2.1 GB in + 2.1 GB out of 288 GB)")
     ap.add_argument("--width", type=int, default=3840)
@@ -373,10 +507,17 @@ def main():
                          "experimental persistent-wave and LDS-tile maps of libhevcdbk_diag.so, never a result)")
     ap.add_argument("--diag", default=None,
                     help="load libhevcdbk_diag.so and set these knobs (csrc/hevcdbk_diag.h): A/B runs only, never a result")
-    ap.add_argument("--traffic", choices=["live", "file", "none"], default="live",
-                    help="roofline.traffic: live = PMC passes (rocprofv3) run as child processes before this process touches "
-                         "the GPU (about 20 s); file = newest matching profiles/*_hbm_traffic.json; live falls back to file")
-    ap.add_argument("--no-telemetry", action="store_true", help="do not sample the card's clock / power files during the timed region")
+    ap.add_argument("--traffic", choices=["live", "file", "none"], default="file",
+                    help="roofline.traffic: file = newest matching profiles/*_hbm_traffic.json (collected with tools/hbm_traffic.py); "
+                         "live = the same four rocprofv3 --pmc passes run now as child processes, before this process touches the "
+                         "GPU (about 20 s of GPU time; falls back to file)")
+    ap.add_argument("--copy-floor", choices=["auto", "off"], default="auto",
+                    help="auto: a child process measures the copy variant of the kernel (libhevcdbk_diag.so) on the same workload "
+                         "before this process touches the GPU -> roofline.copy_floor_ms")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than HIP devices (ranks then share devices: rehearsal only, not a scaling figure)")
+    ap.add_argument("--rank-timeout", type=float, default=540.0, help="seconds the self-spawned ranks of --gpus N may run")
+    ap.add_argument("--no-telemetry", action="store_true", help="do not sample the card's clock / power files during the run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and the reference table line")
@@ -386,8 +527,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` by itself: this process becomes the launcher.  It has made no HIP call (the
         # product library is not even loaded yet) and never execs: it starts N fresh children of this script,
-        # one rank per GPU, waits for all of them and fails if any fails.  Rank 0 prints the one JSON line.
-        codes = shard.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        # one rank per GPU, waits for all of them (at most --rank-timeout seconds: a rank stuck in a barrier is
+        # terminated with the others) and fails if any fails.  Rank 0 prints the one JSON line.
+        codes = shard.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], timeout_s=args.rank_timeout)
         bad = [c for c in codes if c != 0]
         if bad:
             print("bench: rank exit codes %s" % codes, file=sys.stderr)
@@ -399,16 +541,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist  # gloo: control plane only, the data path has no collective
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.rank_timeout))
 
     w, h, F, bd = args.width, args.height, args.frames, args.bit_depth
-    traffic = None
-    if world == 1 and args.variant in ("auto", "packed") and args.diag is None and args.map == "auto":
+    default_kernel = args.variant in ("auto", "packed") and args.diag is None and args.map == "auto"
+    # child processes first: this process has not touched the GPU yet
+    traffic, floor = None, None
+    if world == 1 and default_kernel:
+        if args.copy_floor == "auto":
+            floor = copy_floor(args)
         if args.traffic == "live":
-            traffic = live_traffic(w, h, F, bd)   # BEFORE the first HIP call of this process
+            traffic = live_traffic(w, h, F, bd)
         if traffic is None and args.traffic in ("live", "file"):
             traffic = measured_traffic(w, h, F, bd)
     if args.map in ("stripe", "tiles", "pipe", "group") and args.diag is None:
@@ -422,37 +569,59 @@ def main():
     ndev = deblock.device_count()
     if ndev <= 0:
         raise SystemExit("bench.py needs a HIP device: the deblocking filter has no CPU fallback")
-    ctx = deblock.Context(local_rank % ndev)
+    if world > ndev and not args.oversubscribe:
+        raise SystemExit("bench.py: %d ranks but %d HIP device(s) visible -- ranks would share a GPU and the aggregate would not be "
+                         "a scaling figure (pass --oversubscribe to rehearse the multi-rank path on fewer devices)" % (world, ndev))
+    device = local_rank % ndev
+    ctx = deblock.Context(device)
+    try:
+        pci = ctx.pci_bus_id()
+    except deblock.DeblockError:
+        pci = None
     frames = make_frames(w, h, F, bd, seed=1 + rank)
     batch = deblock.DeviceBatch(ctx, w, h, F, bit_depth=bd)
     batch.upload_all(frames)
     planes = batch.planes()
+
+    # everything on the host side BEFORE the first launch: the sampler thread reads this rank's card (PCI id from the
+    # context that is already open) every 10 ms from here to the end of the timed window
+    sampler = None
+    if not args.no_telemetry and pci:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from clock_power_trace import Sampler
+            sampler = Sampler(pci=pci).start()
+        except Exception:
+            sampler = None
 
     def barrier():
         ctx.synchronize()
         if dist is not None:
             dist.barrier()
 
-    if args.settle > 0:
-        ctx.run_timed([planes], args.qp, args.settle, variant=variant)
-    if args.warmup > 0:
-        ctx.run_timed([planes], args.qp, args.warmup, variant=variant)
     barrier()
-    sampler = None
-    if not args.no_telemetry:
-        try:  # engine clock and socket power of THIS rank's card during the timed region (amdgpu sysfs; None where unreadable)
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            from clock_power_trace import Sampler
-            sampler = Sampler(local_rank % ndev).start()
-        except Exception:
-            sampler = None
-    t0 = time.perf_counter()
-    kernel_ms = ctx.run_timed([planes], args.qp, args.steps, variant=variant)  # K launches, one sync at the end
-    ctx.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    telemetry = sampler.stop(t0 + 0.2 * elapsed, t1) if sampler is not None else None
+    if world == 1:
+        kernel_ms, info = ctx.replay([planes], args.qp, args.steps, warmup=args.warmup, settle_min_ms=args.settle_min_ms,
+                                     settle_max_ms=args.settle_max_ms, variant=variant)
+    else:
+        # ranks settle on their own clocks, meet, and then every rank runs [fixed re-settle][warm-up][timed] uninterrupted, so
+        # the timed windows of all ranks overlap (the cards share the host and, on some nodes, a power budget)
+        _ms, info = ctx.replay([planes], args.qp, 0, warmup=0, settle_min_ms=args.settle_min_ms, settle_max_ms=args.settle_max_ms,
+                               variant=variant)
+        barrier()
+        resettle = 100.0 if args.settle_max_ms > 0 else 0.0
+        kernel_ms, info2 = ctx.replay([planes], args.qp, args.steps, warmup=args.warmup, settle_min_ms=resettle,
+                                      settle_max_ms=resettle, variant=variant)
+        info2["settle_ms"] += info["settle_ms"]
+        info2["settle_launches"] += info["settle_launches"]
+        info2["settled"] = info["settled"]
+        info = info2
+    elapsed = info["wall_ms"] * 1e-3
+    # clock / power over the last 150 ms of the settle phase and the timed window: the same uninterrupted stream, already in
+    # the state the timed launches run in (the timed window alone is 17 ms at the driver's --steps 20: one or two samples)
+    telemetry = sampler.stop(info["t_begin"] - 0.15, info["t_end"]) if sampler is not None else None
     barrier()
+    my_elapsed = elapsed
     elapsed = shard.max_over_ranks(dist, elapsed)  # MAX over ranks (gloo; control plane only)
 
     # parity spot check on what the timed launches wrote (not timed)
@@ -469,14 +638,25 @@ def main():
     roof["traffic"] = traffic[0] if traffic else None
     roof["traffic_source"] = traffic[1] if traffic else None
     roof["read_GBps"] = (abytes - w * h * sb * F) / (roof["kernel_avg_ms"] * 1e-3) / 1e9
-    if telemetry and telemetry.get("samples"):
-        # the filter runs into the socket power cap: the engine clock it gets is part of what bounds it
-        roof["engine_clock_MHz"] = telemetry["engine_clock_MHz"]
-        roof["socket_power_W"] = telemetry["socket_power_W"]
-        roof["power_cap_W"] = telemetry["power_cap_W"]
-        roof["telemetry_samples"] = telemetry["samples"]
-        roof["telemetry_note"] = ("amdgpu sysfs of this rank's card over the last 80 % of the timed region; the power file is a slow "
-                                  "average and reads low in a region this short (tools/clock_power_trace.py holds the load for seconds)")
+    roof["timed_span_ms_gpu_clock"] = info["span_ms"]
+    if floor:
+        roof.update(floor)
+        roof["kernel_over_copy_floor"] = roof["kernel_avg_ms"] / floor["copy_floor_ms"]
+        roof["copy_floor_note"] = ("the kernel's own loads and stores with no arithmetic (diagnostic library), same workload, a child "
+                                   "process of this invocation run before the measurement")
+    n_tel = telemetry.get("samples", 0) if telemetry else 0
+    roof["telemetry_samples"] = n_tel
+    ok_tel = n_tel >= 5
+    # the filter runs into the socket power cap: the engine clock it gets is part of what bounds it
+    roof["engine_clock_MHz"] = telemetry["engine_clock_MHz"] if ok_tel else None
+    roof["socket_power_W"] = telemetry["socket_power_W"] if ok_tel else None
+    roof["power_cap_W"] = telemetry["power_cap_W"] if ok_tel else None
+    roof["telemetry_note"] = ("amdgpu sysfs of this rank's card, medians over the last 150 ms of the settle phase + the timed window (one "
+                              "uninterrupted stream); fewer than 5 samples => null; the power file is a slow average")
+    per_rank = {"rank": rank, "device": device, "pci": pci, "frames_per_s": F * args.steps / my_elapsed,
+                "kernel_avg_ms": roof["kernel_avg_ms"], "kernel_ms_p50": roof["kernel_ms_p50"],
+                "engine_clock_MHz": roof["engine_clock_MHz"], "settle_ms": info["settle_ms"], "bit_exact_vs_oracle": bit_exact}
+    ranks = shard.gather_objects(dist, per_rank)
     out = {
         "metric": "luma_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -485,9 +665,12 @@ def main():
         "config": {"workload": "synthetic %dx%d %d-bit luma deblock, QP %d, default bS, %d frames/GPU/step, device-resident, src->dst"
                                % (w, h, bd, args.qp, F),
                    "frames_per_gpu": F, "kernel_variant": args.variant, "block_map": args.map, "diag": args.diag,
-                   "settle_launches": args.settle, "parallelism": "frame-parallel x%d, no collective" % world},
+                   "settle_ms": info["settle_ms"], "settle_launches": info["settle_launches"], "settled": bool(info["settled"]),
+                   "settle_rule": "trailing 32 launches within 0.5 %% of the 32 before, %g..%g ms" % (args.settle_min_ms, args.settle_max_ms),
+                   "oversubscribed": world > ndev,
+                   "parallelism": "frame-parallel x%d, no collective" % world},
         "bit_exact_vs_oracle": bit_exact, "diagnostic_copy_only": args.variant == "copy",
-        "roofline": roof,
+        "roofline": roof, "per_rank": ranks,
     }
     if rank == 0 and world == 1 and args.variant != "copy" and args.diag is None:
         if not args.no_extra:
@@ -531,7 +714,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     extras_ok = all(v.get("bit_exact_vs_oracle", True) for v in out.get("extra_configs", {}).values())
-    if not bit_exact or not extras_ok:
+    if not bit_exact or not extras_ok or not all(r.get("bit_exact_vs_oracle", True) for r in ranks):
         raise SystemExit("bench: HIP output differs from the oracle")
 
 

@@ -32,7 +32,8 @@ EXPORTS = [
     "hevc_deblocking_filter_sequence",
     "hevcdbk_device_malloc", "hevcdbk_device_free", "hevcdbk_host_malloc_pinned", "hevcdbk_host_free_pinned",
     "hevcdbk_memcpy_h2d", "hevcdbk_memcpy_d2h", "hevcdbk_memcpy_d2d", "hevcdbk_memset_d",
-    "hevcdbk_synchronize", "hevcdbk_compute_stream", "hevcdbk_device_run_timed", "hevcdbk_execute_gpu",
+    "hevcdbk_synchronize", "hevcdbk_compute_stream", "hevcdbk_device_run_timed", "hevcdbk_device_replay",
+    "hevcdbk_device_pci_bus_id", "hevcdbk_execute_gpu",
     "hevcdbk_filter_yuv_file", "hevcdbk_filter_yuv_file_multi",
     "hevcdbk_h265_num_vert_bs", "hevcdbk_h265_num_hor_bs", "hevcdbk_h265_derive_bs_device",
     "hevc_deblocking_filter_h265_device", "hevc_deblocking_filter_h265", "hevc_sao_filter_device",
@@ -57,6 +58,15 @@ class Qp(C.Structure):
 
 class Tables(C.Structure):
     _fields_ = [("tc", C.c_void_p), ("beta", C.c_void_p)]
+
+
+class Replay(C.Structure):
+    """hevcdbk_replay: in = settle / warm-up / steps, out = what the settle phase did and the timed window's brackets"""
+    _fields_ = [("settle_min_ms", C.c_double), ("settle_max_ms", C.c_double), ("settle_tolerance", C.c_double),
+                ("settle_window", C.c_uint), ("warmup", C.c_uint), ("steps", C.c_uint),
+                ("settle_launches", C.c_uint), ("settled", C.c_int), ("settle_ms", C.c_double),
+                ("settle_tail_mean_ms", C.c_double), ("t_begin", C.c_double), ("t_end", C.c_double),
+                ("wall_ms", C.c_double), ("span_ms", C.c_double)]
 
 
 class Timing(C.Structure):
@@ -159,6 +169,9 @@ def lib():
         L.hevcdbk_compute_stream.restype = C.c_void_p
         L.hevcdbk_device_run_timed.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint, C.c_uint,
                                                C.POINTER(Tables), C.c_int, C.c_uint, C.POINTER(C.c_float)]
+        L.hevcdbk_device_replay.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint, C.c_uint,
+                                            C.POINTER(Tables), C.c_int, C.POINTER(Replay), C.POINTER(C.c_float)]
+        L.hevcdbk_device_pci_bus_id.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.hevcdbk_execute_gpu.argtypes = [C.c_char_p, C.c_char_p, C.c_uint, C.c_uint, C.c_uint,
                                           C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int]
         L.hevcdbk_filter_yuv_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint, C.c_uint, C.c_uint,

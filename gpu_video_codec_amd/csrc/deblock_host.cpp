@@ -18,6 +18,8 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cmath>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -530,24 +532,59 @@ int hevc_deblocking_filter_device(hevcdbk_context *ctx, const hevcdbk_device_pla
     return launch(ctx, a, (int)planes->sample_bytes, planes->is_chroma != 0, kernel_variant, s);
 }
 
-/* the planes of a batch: one fused launch where the fused kernel applies, else plane by plane */
-static int launch_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, const DbkArgs *args, unsigned n_planes,
-                         int kernel_variant, hipStream_t s)
+/* would launch() accept this plane?  (the checks launch() makes before it enqueues anything) */
+static int check_launch(const DbkArgs &a, int sample_bytes, bool chroma, int variant)
+{
+    const int map = variant & HEVCDBK_MAP_MASK, fam = variant & ~HEVCDBK_MAP_MASK;
+#ifdef HEVCDBK_DIAG
+    if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR && map != HEVCDBK_DIAG_MAP_TILES && map != HEVCDBK_DIAG_MAP_STRIPE && map != HEVCDBK_DIAG_MAP_PIPE && map != HEVCDBK_DIAG_MAP_GROUP) return HEVCDBK_ERR_ARG;
+    if (fam == HEVCDBK_DIAG_KERNEL_COPY) return dbk_packed_supports(a, sample_bytes, chroma) ? HEVCDBK_OK : HEVCDBK_ERR_UNSUPPORTED;
+#else
+    if (map != HEVCDBK_MAP_AUTO && map != HEVCDBK_MAP_ROWS && map != HEVCDBK_MAP_LINEAR) return HEVCDBK_ERR_ARG;
+#endif
+    if (fam == HEVCDBK_KERNEL_PACKED) return dbk_packed_supports(a, sample_bytes, chroma) ? HEVCDBK_OK : HEVCDBK_ERR_UNSUPPORTED;
+    if (fam == HEVCDBK_KERNEL_GENERIC || fam == HEVCDBK_KERNEL_AUTO) return HEVCDBK_OK;
+    return HEVCDBK_ERR_ARG;
+}
+
+/* true when the planes of a batch go out as ONE fused launch (dbk_packed_multi_kernel / dbk_packed16_multi_kernel) */
+static bool planes_fuse(const hevcdbk_device_planes *planes, const DbkArgs *args, unsigned n_planes, int kernel_variant, int *sb0)
 {
     const int fam = kernel_variant & ~HEVCDBK_MAP_MASK, map = kernel_variant & HEVCDBK_MAP_MASK;
-    if (n_planes >= 2 && n_planes <= 3 && map == HEVCDBK_MAP_AUTO && (fam == HEVCDBK_KERNEL_AUTO || fam == HEVCDBK_KERNEL_PACKED) &&
-        !planes[0].is_chroma) {
-        int sbs[3] = {0, 0, 0};
-        bool ok = true;
-        for (unsigned i = 0; i < n_planes; i++) {
-            sbs[i] = (int)planes[i].sample_bytes;
-            ok = ok && (i == 0 || planes[i].is_chroma) && dbk_packed_supports(args[i], sbs[i], planes[i].is_chroma != 0);
-        }
-        if (ok && dbk_multi_supports(args, (int)n_planes, sbs))
-            return hip_ok(ctx, dbk_launch_packed_multi(args, (int)n_planes, sbs[0], s), "kernel launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    if (n_planes < 2 || n_planes > 3 || map != HEVCDBK_MAP_AUTO || (fam != HEVCDBK_KERNEL_AUTO && fam != HEVCDBK_KERNEL_PACKED) ||
+        planes[0].is_chroma)
+        return false;
+    int sbs[3] = {0, 0, 0};
+    for (unsigned i = 0; i < n_planes; i++) {
+        sbs[i] = (int)planes[i].sample_bytes;
+        if (!((i == 0 || planes[i].is_chroma) && dbk_packed_supports(args[i], sbs[i], planes[i].is_chroma != 0))) return false;
+    }
+    *sb0 = sbs[0];
+    return dbk_multi_supports(args, (int)n_planes, sbs);
+}
+
+/* the planes of a batch: one fused launch where the fused kernel applies, else plane by plane.  Every plane is checked
+ * BEFORE the first launch, so an unsupported operand returns its error with nothing enqueued (no partly written dst).
+ * ev_start / ev_stop (may be NULL): the step's first launch stamps its own begin into ev_start and its last launch its own
+ * end into ev_stop -- kernel time as a profiler's kernel trace sees it, no barrier packets between the launches. */
+static int launch_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, const DbkArgs *args, unsigned n_planes,
+                         int kernel_variant, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
+{
+    int sb0 = 0;
+    if (planes_fuse(planes, args, n_planes, kernel_variant, &sb0)) {
+        dbk_set_next_launch_events(ev_start, ev_stop);
+        const hipError_t e = dbk_launch_packed_multi(args, (int)n_planes, sb0, s);
+        dbk_set_next_launch_events(nullptr, nullptr);
+        return hip_ok(ctx, e, "kernel launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
     }
     for (unsigned i = 0; i < n_planes; i++)
-        if (int rc = launch(ctx, args[i], (int)planes[i].sample_bytes, planes[i].is_chroma != 0, kernel_variant, s)) return rc;
+        if (int rc = check_launch(args[i], (int)planes[i].sample_bytes, planes[i].is_chroma != 0, kernel_variant)) return rc;
+    for (unsigned i = 0; i < n_planes; i++) {
+        dbk_set_next_launch_events(i == 0 ? ev_start : nullptr, i + 1 == n_planes ? ev_stop : nullptr);
+        const int rc = launch(ctx, args[i], (int)planes[i].sample_bytes, planes[i].is_chroma != 0, kernel_variant, s);
+        dbk_set_next_launch_events(nullptr, nullptr);
+        if (rc) return rc;
+    }
     return HEVCDBK_OK;
 }
 
@@ -564,56 +601,141 @@ int hevc_deblocking_filter_device_planes(hevcdbk_context *ctx, const hevcdbk_dev
     return launch_planes(ctx, planes, args, n_planes, kernel_variant, hip_stream ? (hipStream_t)hip_stream : ctx->compute);
 }
 
-int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
-                             unsigned qp, const hevcdbk_tables *tables, int kernel_variant, unsigned steps,
-                             float *kernel_ms)
+static int ensure_timed_events(hevcdbk_context *ctx, size_t need)
 {
-    if (!ctx || !planes || n_planes == 0 || !kernel_ms) return HEVCDBK_ERR_ARG;
-    std::vector<DbkArgs> args(n_planes);
-    for (unsigned i = 0; i < n_planes; i++)
-        if (int rc = planes_to_args(&planes[i], qp, tables, args[i])) return rc;
-    if (int rc = bind(ctx)) return rc;
-    const size_t need = 2 * (size_t)steps;
     while (ctx->timed_events.size() < need) {
         hipEvent_t e;
         HIP_TRY(ctx, hipEventCreate(&e));
         ctx->timed_events.push_back(e);
     }
-    /* the step's first launch stamps its own begin and the last one its own end into the events: kernel time as a
-     * profiler's kernel trace sees it, and no barrier packets between the launches */
-    /* a step = hevc_deblocking_filter_device_planes over the planes handed in (one fused launch where that applies) */
-    bool same_frames = n_planes <= 3;
-    for (unsigned i = 1; i < n_planes; i++) same_frames = same_frames && planes[i].n_frames == planes[0].n_frames;
-    for (unsigned s = 0; s < steps; s++) {
-        if (same_frames) {
-            /* probe once whether the step is ONE launch: then that launch stamps both events */
-            int sbs[3] = {0, 0, 0};
-            bool fused = n_planes >= 2 && !planes[0].is_chroma && (kernel_variant & HEVCDBK_MAP_MASK) == HEVCDBK_MAP_AUTO &&
-                         ((kernel_variant & ~HEVCDBK_MAP_MASK) == HEVCDBK_KERNEL_AUTO || (kernel_variant & ~HEVCDBK_MAP_MASK) == HEVCDBK_KERNEL_PACKED);
-            for (unsigned i = 0; i < n_planes && fused; i++) {
-                sbs[i] = (int)planes[i].sample_bytes;
-                fused = (i == 0 || planes[i].is_chroma) && dbk_packed_supports(args[i], sbs[i], planes[i].is_chroma != 0);
+    return HEVCDBK_OK;
+}
+
+static double monotonic_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
+                             unsigned qp, const hevcdbk_tables *tables, int kernel_variant, unsigned steps,
+                             float *kernel_ms)
+{
+    if (!ctx || !planes || n_planes == 0 || n_planes > 3 || !kernel_ms) return HEVCDBK_ERR_ARG;
+    hevcdbk_replay r;
+    std::memset(&r, 0, sizeof(r));
+    r.steps = steps;
+    return hevcdbk_device_replay(ctx, planes, n_planes, qp, tables, kernel_variant, &r, kernel_ms);
+}
+
+/*
+ * One uninterrupted stream of launches: [settle ...][warm-up x W][timed x K], one synchronisation at the very end.
+ *
+ * Settling is by TIME, not by count: the clock governor works in milliseconds (the card idles at a few hundred MHz and needs
+ * tens of milliseconds under load to reach the state it then holds; under this VALU-heavy kernel it ends at the socket power
+ * cap).  Launches are issued until the mean duration of the trailing `settle_window` launches lies within
+ * `settle_tolerance` of the mean of the window before it, but for no less than settle_min_ms and no more than settle_max_ms.
+ * The host reads the per-launch durations from events of launches that have already completed while it stays up to
+ * kAhead launches ahead of the GPU, so the queue never drains between the phases.
+ */
+int hevcdbk_device_replay(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes, unsigned qp,
+                          const hevcdbk_tables *tables, int kernel_variant, hevcdbk_replay *r, float *kernel_ms)
+{
+    if (!ctx || !planes || n_planes == 0 || n_planes > 3 || !r || (r->steps && !kernel_ms)) return HEVCDBK_ERR_ARG;
+    if (r->settle_min_ms < 0 || r->settle_max_ms < r->settle_min_ms || r->settle_tolerance < 0) return HEVCDBK_ERR_ARG;
+    DbkArgs args[3];
+    for (unsigned i = 0; i < n_planes; i++) {
+        if (int rc = planes_to_args(&planes[i], qp, tables, args[i])) return rc;
+        if (planes[i].n_frames != planes[0].n_frames) return HEVCDBK_ERR_ARG;
+    }
+    if (int rc = bind(ctx)) return rc;
+    constexpr unsigned kRing = 256, kAhead = 48;
+    const unsigned steps = r->steps, warm = r->warmup;
+    /* events: [0, 2*kRing) the settle ring, then one pair per warm-up and timed launch */
+    if (int rc = ensure_timed_events(ctx, 2 * (size_t)kRing + 2 * ((size_t)warm + steps))) return rc;
+    hipEvent_t *ev = ctx->timed_events.data();
+    const unsigned W = r->settle_window ? r->settle_window : 32;
+    const double tol = r->settle_tolerance > 0 ? r->settle_tolerance : 0.005;
+
+    r->settle_launches = 0; r->settle_ms = 0; r->settled = 0; r->settle_tail_mean_ms = 0;
+    std::vector<float> hist; /* durations of completed settle launches, in launch order */
+    unsigned launched = 0, read = 0;
+    const double t_first = monotonic_s();
+    bool stop = !(r->settle_max_ms > 0);
+    auto harvest = [&](bool block) -> int {
+        while (read < launched) {
+            hipEvent_t e0 = ev[2 * (read % kRing)], e1 = ev[2 * (read % kRing) + 1];
+            if (block) HIP_TRY(ctx, hipEventSynchronize(e1));
+            else {
+                const hipError_t q = hipEventQuery(e1);
+                if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
+                if (!hip_ok(ctx, q, "hipEventQuery")) return HEVCDBK_ERR_HIP;
             }
-            fused = fused && dbk_multi_supports(args.data(), (int)n_planes, sbs);
-            if (fused || n_planes == 1) {
-                dbk_set_next_launch_events(ctx->timed_events[2 * s], ctx->timed_events[2 * s + 1]);
-                const int rc = launch_planes(ctx, planes, args.data(), n_planes, kernel_variant, ctx->compute);
-                dbk_set_next_launch_events(nullptr, nullptr);
-                if (rc) return rc;
-                continue;
-            }
+            float ms = 0;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+            hist.push_back(ms);
+            read++;
+            block = false;
         }
-        for (unsigned i = 0; i < n_planes; i++) {
-            dbk_set_next_launch_events(i == 0 ? ctx->timed_events[2 * s] : nullptr,
-                                       i + 1 == n_planes ? ctx->timed_events[2 * s + 1] : nullptr);
-            const int rc = launch(ctx, args[i], (int)planes[i].sample_bytes, planes[i].is_chroma != 0, kernel_variant, ctx->compute);
-            dbk_set_next_launch_events(nullptr, nullptr);
-            if (rc) return rc;
+        return HEVCDBK_OK;
+    };
+    while (!stop) {
+        if (launched - read >= kAhead) { if (int rc = harvest(true)) return rc; }
+        if (int rc = launch_planes(ctx, planes, args, n_planes, kernel_variant, ctx->compute, ev[2 * (launched % kRing)],
+                                   ev[2 * (launched % kRing) + 1]))
+            return rc;
+        launched++;
+        if (int rc = harvest(false)) return rc;
+        const double el_ms = (monotonic_s() - t_first) * 1e3;
+        if (el_ms >= r->settle_max_ms) stop = true;
+        else if (el_ms >= r->settle_min_ms && hist.size() >= 2 * (size_t)W) {
+            double a = 0, b = 0;
+            for (unsigned i = 0; i < W; i++) { a += hist[hist.size() - 1 - i]; b += hist[hist.size() - 1 - W - i]; }
+            if (std::fabs(a - b) <= tol * b) { stop = true; r->settled = 1; }
         }
     }
+    r->settle_launches = launched;
+    r->settle_ms = launched ? (monotonic_s() - t_first) * 1e3 : 0.0;
+
+    /* warm-up and timed launches go out behind the settle launches still in flight */
+    hipEvent_t *tev = ev + 2 * (size_t)kRing;
+    for (unsigned s = 0; s < warm + steps; s++)
+        if (int rc = launch_planes(ctx, planes, args, n_planes, kernel_variant, ctx->compute, tev[2 * s], tev[2 * s + 1])) return rc;
+    /* front bracket of the timed window: the host observes the end of the launch BEFORE the first timed one while the timed
+     * launches are already queued behind it (no idle gap on the GPU); with nothing in front of them, a stream
+     * synchronisation before the first launch would be the bracket -- the queue is empty then anyway */
+    if (warm > 0) HIP_TRY(ctx, hipEventSynchronize(tev[2 * (warm - 1) + 1]));
+    else if (launched > 0) HIP_TRY(ctx, hipEventSynchronize(ev[2 * ((launched - 1) % kRing) + 1]));
+    r->t_begin = (warm > 0 || launched > 0) ? monotonic_s() : t_first;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
+    r->t_end = monotonic_s();
+    r->wall_ms = (r->t_end - r->t_begin) * 1e3;
     for (unsigned s = 0; s < steps; s++)
-        HIP_TRY(ctx, hipEventElapsedTime(&kernel_ms[s], ctx->timed_events[2 * s], ctx->timed_events[2 * s + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&kernel_ms[s], tev[2 * (warm + s)], tev[2 * (warm + s) + 1]));
+    r->span_ms = 0;
+    if (steps) {
+        float sp = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&sp, tev[2 * warm], tev[2 * (warm + steps - 1) + 1]));
+        r->span_ms = sp;
+    }
+    if (int rc = harvest(true)) return rc; /* everything has completed: the tail of the settle phase */
+    if (!hist.empty()) {
+        const size_t n = hist.size() < W ? hist.size() : W;
+        double a = 0;
+        for (size_t i = 0; i < n; i++) a += hist[hist.size() - 1 - i];
+        r->settle_tail_mean_ms = a / (double)n;
+    }
+    return HEVCDBK_OK;
+}
+
+int hevcdbk_device_pci_bus_id(const hevcdbk_context *ctx, char *buf, size_t len)
+{
+    if (!ctx || !buf || len < 13) return HEVCDBK_ERR_ARG;
+    if (hipDeviceGetPCIBusId(buf, (int)len, ctx->device) != hipSuccess) {
+        (void)hipGetLastError();
+        return HEVCDBK_ERR_HIP;
+    }
     return HEVCDBK_OK;
 }
 

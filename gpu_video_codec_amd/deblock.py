@@ -359,6 +359,28 @@ class Context:
         _chk(rc, self.handle)
         return np.array(ms, np.float64)
 
+    def replay(self, planes_list, qp, steps, *, warmup=0, settle_min_ms=150.0, settle_max_ms=2000.0, settle_tolerance=0.005,
+               settle_window=32, variant=KERNEL_AUTO, tc_table=None, beta_table=None):
+        """hevcdbk_device_replay: ONE uninterrupted stream of [settle by time][warmup][steps timed] launches, one
+        synchronisation at the end.  Returns (per-launch kernel ms of the timed launches, dict of the replay's outputs)."""
+        arr = (_lib.DevicePlanes * len(planes_list))(*planes_list)
+        ms = (C.c_float * max(steps, 1))()
+        t, _k = _tables(tc_table, beta_table)
+        r = _lib.Replay(settle_min_ms=settle_min_ms, settle_max_ms=settle_max_ms, settle_tolerance=settle_tolerance,
+                        settle_window=settle_window, warmup=warmup, steps=steps)
+        rc = _lib.lib().hevcdbk_device_replay(self.handle, arr, len(planes_list), int(qp),
+                                              None if t is None else C.byref(t), variant, C.byref(r), ms)
+        _chk(rc, self.handle)
+        info = {k: getattr(r, k) for k in ("settle_launches", "settled", "settle_ms", "settle_tail_mean_ms", "t_begin", "t_end",
+                                           "wall_ms", "span_ms")}
+        return np.array(ms[:steps], np.float64), info
+
+    def pci_bus_id(self):
+        """'0000:0a:00.0' of this context's device (hevcdbk_device_pci_bus_id), lower case"""
+        buf = C.create_string_buffer(64)
+        _chk(_lib.lib().hevcdbk_device_pci_bus_id(self.handle, buf, 64), self.handle)
+        return buf.value.decode().lower()
+
 
 class DeviceBatch:
     """n_frames planes of identical geometry resident in HBM (src and dst), plus their bS arrays.

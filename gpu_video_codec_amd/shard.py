@@ -87,6 +87,17 @@ def max_over_ranks(dist, value):
     return float(t.item())
 
 
+def gather_objects(dist, obj):
+    """Every rank contributes one picklable object; returns the list over ranks, in rank order, on every rank
+    (bench.py: the per-rank line -- device, PCI id, rate, kernel time, engine clock -- so that a straggling GPU of an
+    N-GPU run is visible in rank 0's one JSON line, which otherwise carries only the max elapsed)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, obj)
+    return parts
+
+
 def gather_frame_results(dist, local, n_frames):
     """Test/verification helper: every rank contributes {frame_index: sha256 hex}; returns the merged
     dict on every rank.  Used to check that an N-GPU run equals the 1-GPU run frame by frame."""

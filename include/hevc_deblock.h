@@ -213,10 +213,42 @@ HEVCDBK_API void *hevcdbk_compute_stream(hevcdbk_context *ctx); /* hipStream_t *
 
 /* Timed replay for benchmarks: launches the device operator `steps` times back-to-back on the
  * compute stream with a HIP event pair around EACH launch, synchronises once at the end and
- * writes the per-launch kernel durations (milliseconds) to kernel_ms[steps]. */
+ * writes the per-launch kernel durations (milliseconds) to kernel_ms[steps].  (= hevcdbk_device_replay with no
+ * settling and no warm-up.)  The timing window is the reference's "execution time without copy": kernels + one
+ * synchronisation, nothing else (gpu.cu:1266-1291). */
 HEVCDBK_API int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
                              unsigned qp, const hevcdbk_tables *tables, int kernel_variant,
                              unsigned steps, float *kernel_ms);
+
+/* Steady-state replay: ONE uninterrupted stream of [settle launches][warmup launches][steps timed launches] of the device
+ * operator on the compute stream, one synchronisation at the very end (same window semantics as above).  Settling is by
+ * time: launches go out until the mean duration of the trailing settle_window launches is within settle_tolerance of the
+ * mean of the window before it, for at least settle_min_ms and at most settle_max_ms (settle_max_ms == 0: no settling;
+ * settle_min_ms == settle_max_ms: a fixed time).  The host stays ahead of the GPU throughout, so the queue never drains
+ * between the phases; the front bracket of the timed window is the host observing the end of the last launch before it. */
+typedef struct {
+    /* in */
+    double settle_min_ms, settle_max_ms;
+    double settle_tolerance;   /* relative; 0 => 0.005 */
+    unsigned settle_window;    /* launches; 0 => 32 */
+    unsigned warmup, steps;
+    /* out */
+    unsigned settle_launches;  /* launches the settle phase issued */
+    int settled;               /* 1: the criterion was met before settle_max_ms */
+    double settle_ms;          /* host time the settle phase took to issue */
+    double settle_tail_mean_ms;/* mean duration of its last settle_window launches */
+    double t_begin, t_end;     /* CLOCK_MONOTONIC seconds: end of the launch before the first timed one as seen by the
+                                * host / return of the final synchronisation */
+    double wall_ms;            /* (t_end - t_begin) * 1e3: host wall clock of the `steps` timed launches */
+    double span_ms;            /* GPU timestamps: begin of the first timed launch -> end of the last one */
+} hevcdbk_replay;
+HEVCDBK_API int hevcdbk_device_replay(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
+                          unsigned qp, const hevcdbk_tables *tables, int kernel_variant, hevcdbk_replay *replay,
+                          float *kernel_ms /* [replay->steps] */);
+
+/* PCI bus id ("0000:0a:00.0") of the context's device, for hosts that read the card's sysfs files (clock / power telemetry);
+ * replaces nothing in the reference (GetGpuDeviceInfo, main.cu:92-107, prints properties only).  len >= 13. */
+HEVCDBK_API int hevcdbk_device_pci_bus_id(const hevcdbk_context *ctx, char *buf, size_t len);
 
 /* ---- main.cu-shaped harness entry: replaces ExecuteGpu (main.cu:87-90, gpu.cu:1230-1306) ----
  * file in -> filter Y,U,V on the GPU -> file out, printing the reference's three lines.

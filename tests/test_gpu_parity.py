@@ -358,6 +358,47 @@ def test_error_codes_on_device(ctx, oracle):
     b.free()
 
 
+def test_replay_settles_warms_up_and_times(ctx, oracle):
+    """hevcdbk_device_replay (what bench.py times with): settle by time, warm-up and timed launches as one stream; the
+    per-launch times, the wall clock of the timed window and the GPU-clock span agree, and dst holds the filtered frames."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    y = np.stack([synth.blocky_plane(352, 288, seed=5, frame=f) for f in range(3)])
+    b = deblock.DeviceBatch(ctx, 352, 288, 3)
+    b.upload_all(y)
+    ms, info = ctx.replay([b.planes()], 30, 7, warmup=2, settle_min_ms=5.0, settle_max_ms=60.0)
+    assert ms.shape == (7,) and np.all(ms > 0) and np.all(ms < 50)
+    assert info["settle_launches"] >= 64 and 5.0 <= info["settle_ms"] <= 500.0 and info["settle_tail_mean_ms"] > 0
+    assert info["t_end"] > info["t_begin"] and abs(info["wall_ms"] - (info["t_end"] - info["t_begin"]) * 1e3) < 1e-6
+    assert info["span_ms"] >= ms.sum() * 0.999 and info["span_ms"] < 50        # launches of one stream do not overlap
+    assert info["wall_ms"] >= info["span_ms"] * 0.5                             # same window, seen from the host
+    for f in range(3):
+        assert np.array_equal(b.download_frame(f), oracle.filter_plane(y[f], 30))
+    # no settling, no warm-up = hevcdbk_device_run_timed
+    ms2 = ctx.run_timed([b.planes()], 30, 4)
+    ms3, info3 = ctx.replay([b.planes()], 30, 4, warmup=0, settle_min_ms=0.0, settle_max_ms=0.0)
+    assert ms2.shape == ms3.shape == (4,) and info3["settle_launches"] == 0 and not info3["settled"]
+    # a fixed settling time (what the ranks of a multi-GPU run do after their barrier) and zero timed steps
+    _none, info4 = ctx.replay([b.planes()], 30, 0, warmup=0, settle_min_ms=20.0, settle_max_ms=20.0)
+    assert 20.0 <= info4["settle_ms"] < 200.0 and info4["settle_launches"] > 0
+    # an operand the forced kernel family does not take fails before ANYTHING is enqueued (ADVICE r02: plane 0 used to be
+    # queued -- dst partly written -- when plane 1 was refused): 14-bit chroma is beyond the packed kernels
+    u = deblock.DeviceBatch(ctx, 176, 144, 3, is_chroma=True, bit_depth=14)
+    u.upload_all(np.stack([synth.blocky_plane(176, 144, seed=9, frame=f, bit_depth=14) for f in range(3)]))
+    marker = np.full(b.frame_bytes * 3, 0xA5, np.uint8)
+    b.dst.upload(marker)
+    with pytest.raises(deblock.DeblockError) as e:
+        ctx.filter_device_planes([b.planes(), u.planes()], 30, variant=_lib.KERNEL_PACKED)
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    ctx.synchronize()
+    assert np.all(b.download_frame(0) == 0xA5) and np.all(b.download_frame(2) == 0xA5)
+    ctx.filter_device_planes([b.planes(), u.planes()], 30)    # AUTO: plane by plane, packed luma + 32-bit chroma kernel
+    ctx.synchronize()
+    assert np.array_equal(b.download_frame(1), oracle.filter_plane(y[1], 30))
+    assert ctx.pci_bus_id().count(":") == 2
+    b.free()
+    u.free()
+
+
 def test_row_major_mapping_forced(ctx, oracle):
     """The row-major (linear) block mapping is chosen automatically only for rows wider than one
     workgroup (8K); force it (HEVCDBK_MAP_LINEAR of the kernel selector) on small, ragged and multi-frame

@@ -81,10 +81,11 @@ assert os.environ["LOCAL_RANK"] == str(rank) and os.environ["MASTER_ADDR"] == "1
 dist.init_process_group("gloo", rank=rank, world_size=world)
 dist.barrier()
 t = shard.max_over_ranks(dist, 10.0 + rank)
+per_rank = shard.gather_objects(dist, {"rank": rank, "device": rank, "frames_per_s": 100.0 * (rank + 1)})
 dist.barrier()
 dist.destroy_process_group()
 with open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w") as fh:
-    json.dump({"rank": rank, "world": world, "tmax": t, "pid": os.getpid(), "ppid": os.getppid()}, fh)
+    json.dump({"rank": rank, "world": world, "tmax": t, "pid": os.getpid(), "ppid": os.getppid(), "per_rank": per_rank}, fh)
 """
 
 _CHILD_FAIL = r"""
@@ -105,6 +106,9 @@ def test_spawn_ranks_starts_n_fresh_processes(tmp_path):
     got = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(3)]
     assert [g["rank"] for g in got] == [0, 1, 2] and all(g["world"] == 3 for g in got)
     assert all(g["tmax"] == 12.0 for g in got)                     # max over ranks of 10 + rank
+    # every rank holds every rank's line, in rank order (bench.py's `per_rank`: a straggling GPU is visible on rank 0)
+    assert all(g["per_rank"] == [{"rank": r, "device": r, "frames_per_s": 100.0 * (r + 1)} for r in range(3)] for g in got)
+    assert shard.gather_objects(None, {"rank": 0}) == [{"rank": 0}]
     assert len({g["pid"] for g in got}) == 3                       # three distinct processes ...
     assert all(g["ppid"] == os.getpid() and g["pid"] != os.getpid() for g in got)  # ... children, not an exec of the caller
 
@@ -132,7 +136,7 @@ def test_bench_gpus_flag_spawns_before_any_gpu_call(tmp_path, monkeypatch):
     calls = []
 
     def fake_spawn(world, argv, **kw):
-        calls.append((world, list(argv), None))
+        calls.append((world, list(argv), kw))
         return [0] * world
 
     monkeypatch.setattr(shard, "spawn_ranks", fake_spawn)
@@ -140,7 +144,8 @@ def test_bench_gpus_flag_spawns_before_any_gpu_call(tmp_path, monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
     bench.main()
     assert len(calls) == 1
-    world, argv, _ = calls[0]
+    world, argv, kw = calls[0]
+    assert kw.get("timeout_s") == 540.0      # a rank stuck in a barrier is terminated, not waited for until the driver kills the job
     assert world == 2 and argv[0] == sys.executable and argv[1].endswith("bench.py")
     assert argv[2:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
 
@@ -180,3 +185,38 @@ def test_clock_power_sampler_without_a_card():
     r = s.stop()
     assert r["samples"] == 0 and r["engine_clock_MHz"] is None and r["socket_power_W"] is None
     assert _current_mhz("0: 132Mhz\n1: 2400Mhz *\n") == 2400.0 and _current_mhz("") is None
+
+
+def test_bench_child_runner_kills_the_whole_process_group(tmp_path):
+    """bench.py starts its helper measurements (copy floor, live PMC passes) as children in their OWN process group and
+    kills the group on timeout: a grandchild (rocprofv3 -> python) must not survive holding the GPU."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pidfile = tmp_path / "grandchild.pid"
+    child = ("import subprocess, sys, time\n"
+             "g = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)'])\n"
+             "open(%r, 'w').write(str(g.pid))\n"
+             "time.sleep(600)\n" % str(pidfile))
+    t0 = time.monotonic()
+    out, err, rc = bench.run_group([sys.executable, "-c", child], 3)
+    assert rc is None and time.monotonic() - t0 < 30
+    gpid = int(pidfile.read_text())
+    for _ in range(50):
+        try:
+            os.kill(gpid, 0)
+        except ProcessLookupError:
+            break
+        # a killed but not yet reaped grandchild shows as a zombie owned by init: state Z counts as gone
+        try:
+            if open("/proc/%d/stat" % gpid).read().split(") ")[1][0] == "Z":
+                break
+        except OSError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("grandchild %d survived the timeout" % gpid)
+    out, err, rc = bench.run_group([sys.executable, "-c", "print('ok')"], 30)
+    assert rc == 0 and out.strip() == "ok"

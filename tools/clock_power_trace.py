@@ -52,7 +52,8 @@ def _current_mhz(txt):
 
 
 def pci_of_hip_device(index):
-    """'0000:0a:00.0' of HIP device `index` (initialises the HIP runtime in this process), or None"""
+    """'0000:0a:00.0' of HIP device `index` (initialises the HIP runtime in this process), or None.  Script use only:
+    bench.py hands Sampler the id of its open context (hevcdbk_device_pci_bus_id) instead."""
     try:
         import ctypes
         hip = ctypes.CDLL("libamdhip64.so")
@@ -79,7 +80,7 @@ class Sampler:
         self._thr = None
 
     def read_once(self):
-        r = {"t": time.perf_counter()}
+        r = {"t": time.monotonic()}  # CLOCK_MONOTONIC: the clock hevcdbk_device_replay stamps t_begin / t_end with
         for k, p in self.files.items():
             v = _rd(p)
             if k.startswith("pp_dpm"):

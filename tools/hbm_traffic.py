@@ -31,7 +31,7 @@ def run_pmc(counter, variant, frames, outdir, steps=3, extra=()):
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1",
            "--variant", variant, "--frames", str(frames), "--no-cpu-baseline", "--no-e2e", "--no-extra", "--traffic", "none",
-           "--settle", "5"] + list(extra)
+           "--settle-max-ms", "0", "--copy-floor", "off", "--no-telemetry"] + list(extra)
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     vals = []

@@ -28,7 +28,7 @@ def main():
     for i, ctrs in enumerate(PASSES):
         d = os.path.join(outdir, "%s_pass%d" % (tag, i))
         cmd = ["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--settle", "20", "--variant", args.variant,
+               os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--settle-max-ms", "20", "--copy-floor", "off", "--no-telemetry", "--variant", args.variant,
                "--frames", str(args.frames), "--no-cpu-baseline", "--no-e2e", "--no-extra", "--traffic", "none"] + extra
         r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, cwd=ROOT)
         if r.returncode:
