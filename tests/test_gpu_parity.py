@@ -370,7 +370,9 @@ def test_replay_settles_warms_up_and_times(ctx, oracle):
     assert info["settle_launches"] >= 64 and 5.0 <= info["settle_ms"] <= 500.0 and info["settle_tail_mean_ms"] > 0
     assert info["t_end"] > info["t_begin"] and abs(info["wall_ms"] - (info["t_end"] - info["t_begin"]) * 1e3) < 1e-6
     assert info["span_ms"] >= ms.sum() * 0.999 and info["span_ms"] < 50        # launches of one stream do not overlap
-    assert info["wall_ms"] >= info["span_ms"] * 0.5                             # same window, seen from the host
+    # the host's view of the same window: it starts when the host has SEEN the last warm-up launch end (launches this short
+    # are partly over by then) and ends with the synchronisation, so it can be shorter than the GPU-clock span but not much longer
+    assert 0 < info["wall_ms"] < info["span_ms"] + 5.0
     for f in range(3):
         assert np.array_equal(b.download_frame(f), oracle.filter_plane(y[f], 30))
     # no settling, no warm-up = hevcdbk_device_run_timed
