@@ -523,6 +523,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and the reference table line")
     ap.add_argument("--no-config5", action="store_true", help="skip the 8K 10-bit extra config (3.2 GB of host frames)")
     args = ap.parse_args()
+    args.settle_min_ms = min(args.settle_min_ms, args.settle_max_ms)   # --settle-max-ms 0 = no settling at all
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` by itself: this process becomes the launcher.  It has made no HIP call (the

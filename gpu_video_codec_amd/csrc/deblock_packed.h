@@ -43,9 +43,13 @@ DBK_HD pk splat(int v) { return pk{(short)v, (short)v}; }
 DBK_HD pk splat_u(int v) { const uint32_t x = (uint32_t)v & 0xffffu; return bits_pk(x | (x << 16)); }
 /* all-ones / all-zeros in both halves from a lane condition: one v_cndmask, no re-packing */
 DBK_HD pk mask_of(bool c) { return bits_pk(c ? 0xffffffffu : 0u); }
-/* 1 / 0 in both halves from a lane condition: the factor of a packed multiply-add that applies or drops a delta */
+/* 1 / 0 in both halves from a lane condition: the factor of a packed multiply-add that applies or drops a delta.  (Round 3
+ * tried 1 / 0 in the low half only -- a v_cndmask between two inline constants, no v_mov of 0x00010001 -- with the low half
+ * feeding both lanes through op_sel_hi; that needs the multiply-add as inline asm, and the register copies the compiler then
+ * places at the branch joins cost 7 instructions per segment for the 1 saved.  The VOP3 select with the constant in an SGPR
+ * is not encodable: mask + constant are two scalar operands, gfx9 allows one.) */
 DBK_HD pk one_of(bool c) { return bits_pk(c ? 0x00010001u : 0u); }
-/* a * b + c on three registers: v_pk_mad_i16 */
+/* a * b + c on three registers: v_pk_mad_u16 */
 DBK_HD pk mad_vvv(pk a, pk b, pk c) { return a * b + c; }
 
 DBK_HD pk pk_max(pk a, pk b)
@@ -65,6 +69,17 @@ DBK_HD pk pk_min(pk a, pk b)
 #endif
 }
 DBK_HD pk pk_abs(pk a) { return pk_max(a, splat(0) - a); }
+/* max of fields read as UNSIGNED 16-bit numbers (v_pk_max_u16): for fields that carry a 0x8000 bias */
+DBK_HD pk pk_maxu(pk a, pk b)
+{
+#if DBK_DEV
+    typedef unsigned short upk __attribute__((vector_size(4)));
+    return __builtin_bit_cast(pk, __builtin_elementwise_max(__builtin_bit_cast(upk, a), __builtin_bit_cast(upk, b)));
+#else
+    const unsigned short a0 = (unsigned short)a[0], a1 = (unsigned short)a[1], b0 = (unsigned short)b[0], b1 = (unsigned short)b[1];
+    return pk{(short)(a0 > b0 ? a0 : b0), (short)(a1 > b1 ? a1 : b1)};
+#endif
+}
 /* max(a - b, 0) of non-negative fields: ONE v_pk_sub_u16 with the clamp bit (unsigned saturation) */
 DBK_HD pk sub_sat(pk a, pk b)
 {
@@ -86,6 +101,8 @@ DBK_HD pk sub_sat(pk a, pk b)
 DBK_HD pk uadd(pk a, pk b) { return bits_pk(pk_bits(a) + pk_bits(b)); }  /* fields >= 0, sums < 65536 */
 DBK_HD pk usub(pk a, pk b) { return bits_pk(pk_bits(a) - pk_bits(b)); }  /* field-wise a >= b >= 0 */
 DBK_HD pk uaddc(pk a, uint32_t c2) { return bits_pk(pk_bits(a) + c2); }  /* c2 = constant in both fields */
+DBK_HD pk uadd3c(pk a, pk b, uint32_t c2) { return bits_pk(pk_bits(a) + pk_bits(b) + c2); } /* one v_add3_u32 */
+DBK_HD pk uadd3(pk a, pk b, pk c) { return bits_pk(pk_bits(a) + pk_bits(b) + pk_bits(c)); }
 /* |a - b| of non-negative fields without a signed negate: max - min */
 DBK_HD pk absdiff(pk a, pk b) { return usub(pk_max(a, b), pk_min(a, b)); }
 /* a*K + c and a*K + C in ONE v_pk_mad_i16 (K, C small compile-time constants = inline operands).
@@ -110,6 +127,16 @@ DBK_HD pk mad_kc(pk a)
     return d;
 #else
     return a * splat(K) + splat(C);
+#endif
+}
+
+/* (a | b) & c in ONE instruction (v_bitop3_b32; hipcc otherwise emits v_or + v_and, and a 2-cycle op between 4-cycle ops costs 4) */
+DBK_HD uint32_t or_and(uint32_t a, uint32_t b, uint32_t c)
+{
+#if DBK_DEV
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xA8);
+#else
+    return (a | b) & c;
 #endif
 }
 
@@ -185,32 +212,39 @@ struct Decision {
     bool filter; /* cond1 */
     bool strong; /* cond2 && cond3 && cond4 */
     bool cond5, cond6;
-    pk tp, tq;   /* p2 - 2p1 + p0 and q2 - 2q1 + q0 of pair A (signed): the normal filter's p1 / q1 terms start from them */
+    pk tp1, tq1; /* p2 - 2p1 + p0 + 1 and q2 - 2q1 + q0 + 1 of pair A (signed): the normal filter's p1 / q1 terms start here */
 };
 
+/*
+ * Round 3 form.  Everything carries a small constant so that no instruction exists only to add one:
+ *   tp1 = p2 + p0 + 1 - 2*p1 (the "+ 1" is the rounding term of the normal filter's p1 update, cpu.h:1281, and rides in the
+ *         three-operand add that forms p2 + p0);  |tp| + 1 = max(tp1, 2 - tp1)  -- still two instructions;
+ *   every threshold the +1 / +2 reaches is a wave-uniform scalar and moves with it.
+ * |a - b| of unsigned fields = (a -sat b) + (b -sat a) (one of the two is 0): the two saturating subtractions replace
+ * max / min / sub, and the sum rides in the three-operand add that follows anyway.
+ * "field < T" tests: field + (0x8000 - T) has bit 15 set iff field >= T; the bias rides in the same adds.
+ */
 DBK_HD Decision decide(const Taps &a, int beta, int tc)
 {
-    /* |p2 - 2p1 + p0| on lines 0 and 3: one add, one multiply-add, negate, max (four instead of five instructions) */
-    const pk tp = mad_k<-2>(a.p1, uadd(a.p2, a.p0)), tq = mad_k<-2>(a.q1, uadd(a.q2, a.q0));
-    const pk dp = pk_max(tp, splat(0) - tp), dq = pk_max(tq, splat(0) - tq);
     Decision d;
-    d.tp = tp;
-    d.tq = tq;
-    const pk dpq = uadd(dp, dq);
+    const pk tp1 = mad_k<-2>(a.p1, uadd3c(a.p2, a.p0, 0x00010001u)), tq1 = mad_k<-2>(a.q1, uadd3c(a.q2, a.q0, 0x00010001u));
+    const pk dp1 = pk_max(tp1, splat(2) - tp1), dq1 = pk_max(tq1, splat(2) - tq1); /* |.| + 1 on lines 0 and 3 */
+    d.tp1 = tp1;
+    d.tq1 = tq1;
+    const pk dpq2 = uadd(dp1, dq1);                                   /* d(P,i) + d(Q,i) + 2 */
     /* sum of the two halves in the low 16 bits: x + (x >> 16), compared as a 16-bit value */
-    d.filter = lohi_sum(dpq) < (unsigned)beta;                  /* cpu.h:1086-1087 */
-    const pk e = uadd(absdiff(a.p3, a.p0), absdiff(a.q0, a.q3)); /* cpu.h:1104-1105 */
-    const pk f = absdiff(a.p0, a.q0);                            /* cpu.h:1109-1110 */
-    const pk m = pk_max(dpq, e);
-    /* "both halves < T" without extracting them: (0x8000|T-1) - x keeps bit 15 of a half iff x < T */
-    const int b8 = beta >> 3, tc52 = (5 * tc) >> 1;              /* beta/8, 5*tc/2: non-negative => >> is / */
-    const uint32_t k1 = 0x80008000u | ((uint32_t)(b8 - 1) * 0x00010001u);
-    const uint32_t k2 = 0x80008000u | ((uint32_t)(tc52 - 1) * 0x00010001u);
-    const uint32_t ok = (k1 - pk_bits(m)) & (k2 - pk_bits(f)) & 0x80008000u;
-    d.strong = b8 > 0 && tc52 > 0 && ok == 0x80008000u;
-    const unsigned b316 = (unsigned)((3 * beta) >> 4);          /* 3*beta/16 */
-    d.cond5 = lohi_sum(dp) < b316;
-    d.cond6 = lohi_sum(dq) < b316;
+    d.filter = lohi_sum(dpq2) < (unsigned)beta + 4u;                  /* cpu.h:1086-1087 */
+    const int b8 = beta >> 3, tc52 = (5 * tc) >> 1;                   /* beta/8, 5*tc/2: non-negative => >> is / */
+    /* cpu.h:1104-1105: |p3 - p0| + |q0 - q3| (+ 2, to sit beside dpq2) */
+    const pk e2 = uadd3c(uadd3(sub_sat(a.p3, a.p0), sub_sat(a.p0, a.p3), sub_sat(a.q0, a.q3)), sub_sat(a.q3, a.q0), 0x00020002u);
+    const pk m2 = pk_max(dpq2, e2);                                   /* both tested against beta/8 */
+    const uint32_t km = (uint32_t)(0x8000 - b8 - 2) * 0x00010001u, kf = (uint32_t)(0x8000 - tc52) * 0x00010001u;
+    /* bit 15 of a half set <=> that line violates a strong-filter condition (cpu.h:1099-1110) */
+    const uint32_t bad = or_and(pk_bits(uaddc(m2, km)), pk_bits(uadd3c(sub_sat(a.p0, a.q0), sub_sat(a.q0, a.p0), kf)), 0x80008000u);
+    d.strong = b8 > 0 && tc52 > 0 && bad == 0u;
+    const unsigned b316 = (unsigned)((3 * beta) >> 4) + 2u;           /* 3*beta/16 (+ 2: the fields are |.| + 1) */
+    d.cond5 = lohi_sum(dp1) < b316;
+    d.cond6 = lohi_sum(dq1) < b316;
     return d;
 }
 
@@ -302,51 +336,46 @@ DBK_HD pk normal_delta(const Taps &t)
     }
 }
 
-/* normal filter (cpu.h:1251-1354) of one line pair given its delta, up to, but not including, the final Clip2 to
- * [0, max_v]; m5 / m6 = 1 in both halves where cond5 / cond6 hold, else 0 (one_of).  ALL_ON: the caller has established that
+/* normal filter (cpu.h:1251-1354) of one line pair given its delta: the three deltas it applies -- D to p0 / q0 (cpu.h:1256),
+ * dp1 / dq1 to p1 / q1 where cond5 / cond6 hold (cpu.h:1281-1300).  ALL_ON: the caller has established that
  * |delta| < 10*tc (cpu.h:1254) holds in every line of every lane of the wave, so no per-line mask is needed */
+struct NormalD {
+    pk D, dp1, dq1;
+};
 template <bool ALL_ON, bool HAVE_T = false>
-DBK_HD void normal_apply(Taps &t, pk delta, const NormalK &k, pk m5, pk m6, pk tp = pk{0, 0}, pk tq = pk{0, 0})
+DBK_HD NormalD normal_deltas(const Taps &t, pk delta, const NormalK &k, pk tp = pk{0, 0}, pk tq = pk{0, 0})
 {
-    const pk D = pk_min(pk_max(delta, k.negc), k.c);
+    NormalD n;
+    n.D = pk_min(pk_max(delta, k.negc), k.c);
     /* (((p2+p0+1)>>1) - p1 + D) >> 1  ==  (p2 + p0 + 1 - 2*p1 + 2*D) >> 2   (floor of a floor: the dropped
-     * bit of the inner shift is worth 1/4 and cannot carry across an integer).  HAVE_T: p2 + p0 - 2*p1 (and the Q twin) of
-     * this pair is already there from the decisions (pair A) */
+     * bit of the inner shift is worth 1/4 and cannot carry across an integer).  HAVE_T: p2 + p0 + 1 - 2*p1 (and the Q twin)
+     * of this pair is already there from the decisions (pair A) */
     pk ip, iq;
-    if constexpr (HAVE_T) {
-        ip = tp + splat(1);
-        iq = tq + splat(1);
+    if constexpr (HAVE_T) { /* tp / tq already carry the + 1 (decide) */
+        ip = tp;
+        iq = tq;
     } else {
-        ip = mad_k<-2>(t.p1, uaddc(uadd(t.p2, t.p0), 0x00010001u));
-        iq = mad_k<-2>(t.q1, uaddc(uadd(t.q2, t.q0), 0x00010001u));
+        ip = mad_k<-2>(t.p1, uadd3c(t.p2, t.p0, 0x00010001u));
+        iq = mad_k<-2>(t.q1, uadd3c(t.q2, t.q0, 0x00010001u));
     }
-    const pk dp1 = pk_min(pk_max(mad_k<2>(D, ip) >> 2, k.negc2), k.c2);
-    const pk dq1 = pk_min(pk_max(mad_k<-2>(D, iq) >> 2, k.negc2), k.c2);
-    /* m5 / m6 are 1 / 0 factors (one_of): p1 + dp1 * m5 is ONE multiply-add instead of a mask and an add */
-    if constexpr (ALL_ON) {
-        t.p0 = t.p0 + D;
-        t.q0 = t.q0 - D;
-        t.p1 = mad_vvv(dp1, m5, t.p1);
-        t.q1 = mad_vvv(dq1, m6, t.q1);
-    } else {
+    n.dp1 = pk_min(pk_max(mad_k<2>(n.D, ip) >> 2, k.negc2), k.c2);
+    n.dq1 = pk_min(pk_max(mad_k<-2>(n.D, iq) >> 2, k.negc2), k.c2);
+    if constexpr (!ALL_ON) {
         const pk on = (pk_abs(delta) - k.lim) >> 15; /* all ones where |delta| < 10*tc (cpu.h:1254) */
-        const pk Dm = D & on;
-        t.p0 = t.p0 + Dm;
-        t.q0 = t.q0 - Dm;
-        t.p1 = mad_vvv(dp1 & on, m5, t.p1);
-        t.q1 = mad_vvv(dq1 & on, m6, t.q1);
+        n.D = n.D & on;
+        n.dp1 = n.dp1 & on;
+        n.dq1 = n.dq1 & on;
     }
+    return n;
 }
-
-/* true in a lane where a line of the pair fails |delta| < 10*tc: with t = delta + (10*tc - 1) the test is
- * 0 <= t <= 2*(10*tc) - 2 in both halves, compared as UNSIGNED 16-bit numbers (a negative t wraps to >= 32768).
- * 10*tc <= 32767 and |delta| <= 3071 (packed_luma_tc_fits, 12 bit) keep t and the bound inside 16 bits. */
-DBK_HD bool normal_some_line_off(pk delta, const NormalK &k)
+/* m5 / m6 = 1 in both halves where cond5 / cond6 hold, else 0 (one_of): p1 + dp1 * m5 is ONE multiply-add instead of a mask
+ * and an add.  Up to, but not including, the final Clip2 to [0, max_v] */
+DBK_HD void normal_update(Taps &t, const NormalD &n, pk m5, pk m6)
 {
-    const uint32_t lim = pk_bits(k.lim) & 0xffffu;
-    const uint32_t t = pk_bits(delta + bits_pk(pk_bits(k.lim) - 0x00010001u));
-    const uint32_t bound = 2u * lim - 2u; /* tc == 0 never asks */
-    return (t & 0xffffu) > bound || (t >> 16) > bound;
+    t.p0 = t.p0 + n.D;
+    t.q0 = t.q0 - n.D;
+    t.p1 = mad_vvv(n.dp1, m5, t.p1);
+    t.q1 = mad_vvv(n.dq1, m6, t.q1);
 }
 
 /* wave-level "does any active lane say yes": on the GPU one ballot; in the CPU build of this header (one block at a
@@ -370,18 +399,24 @@ template <bool WIDE = false, bool HAVE_T = false>
 DBK_HD void normal_pairs(Taps &a, Taps &b, int tc, pk m5, pk m6, int max_v, pk tp = pk{0, 0}, pk tq = pk{0, 0})
 {
     const NormalK k = normal_k(tc);
-    {
-        const pk da = normal_delta<WIDE>(a);
-        /* the wave-uniform tc == 0 case joins the ballot as a scalar OR (selecting between a scalar `true` and the lane
-         * condition would make the compiler materialise the lane mask in a VGPR and compare it again) */
-        if (tc <= 0 || any_lane(normal_some_line_off(da, k))) normal_apply<false, HAVE_T>(a, da, k, m5, m6, tp, tq);
-        else normal_apply<true, HAVE_T>(a, da, k, m5, m6, tp, tq);
+    const pk da = normal_delta<WIDE>(a), db = normal_delta<WIDE>(b);
+    /* One test for the four lines of the segment, and a conservative one: with P the largest power of two <= 10*tc,
+     * |delta| < P in every line <=> (delta + P) has no bit at or above 2P in any half -- two adds, one OR-AND, one compare
+     * (round 2: the exact test per pair, 3 + 3).  A wave in which some line has P <= |delta| takes the masked form, which is
+     * exact for every line; on picture content |delta| >= 10*tc/2 happens across real edges only.  The wave-uniform tc == 0
+     * case joins the ballot as a scalar OR. */
+    const uint32_t P = tc > 0 ? 1u << (31 - __builtin_clz((unsigned)(10 * tc))) : 1u;
+    const uint32_t wide = or_and(pk_bits(da + bits_pk(P * 0x00010001u)), pk_bits(db + bits_pk(P * 0x00010001u)), 0x00010001u * (0xffffu & ~(2u * P - 1u)));
+    NormalD na, nb;
+    if (tc <= 0 || any_lane(wide != 0u)) {
+        na = normal_deltas<false, HAVE_T>(a, da, k, tp, tq);
+        nb = normal_deltas<false>(b, db, k);
+    } else {
+        na = normal_deltas<true, HAVE_T>(a, da, k, tp, tq);
+        nb = normal_deltas<true>(b, db, k);
     }
-    {
-        const pk db = normal_delta<WIDE>(b);
-        if (tc <= 0 || any_lane(normal_some_line_off(db, k))) normal_apply<false>(b, db, k, m5, m6);
-        else normal_apply<true>(b, db, k, m5, m6);
-    }
+    normal_update(a, na, m5, m6); /* the updates themselves: once, behind the join */
+    normal_update(b, nb, m5, m6);
     const uint32_t over = (pk_bits(a.p0) | pk_bits(a.q0) | pk_bits(a.p1) | pk_bits(a.q1) |
                            pk_bits(b.p0) | pk_bits(b.q0) | pk_bits(b.p1) | pk_bits(b.q1)) &
                           (0x00010001u * (0xffffu & ~(uint32_t)max_v));
@@ -407,7 +442,7 @@ DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc, int max_v = 255, int 
         strong_pair<WIDE>(a, c);
         strong_pair<WIDE>(b, c);
     } else if (ablate != 2) {
-        normal_pairs<WIDE, true>(a, b, tc, one_of(d.cond5), one_of(d.cond6), max_v, d.tp, d.tq);
+        normal_pairs<WIDE, true>(a, b, tc, one_of(d.cond5), one_of(d.cond6), max_v, d.tp1, d.tq1);
     }
     return true;
 }
