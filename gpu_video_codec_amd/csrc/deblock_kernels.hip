@@ -212,6 +212,23 @@ __device__ __forceinline__ dbk::BlockBs load_bs_buffer(const DbkArgs &a, int f, 
     return b;
 }
 
+/* PATH 3 of packed_body (first / last wave of a block row in the row map, 1 <= by <= nby-2 wave-uniform, every lane
+ * active): the scalar-row form of the interior waves; "bx > 0" (hor1) folds into the range check (index -1), "bx <
+ * limit_bx" (hor2) is the one select left */
+__device__ __forceinline__ dbk::BlockBs load_bs_buffer_rowedge(const DbkArgs &a, int f, int by, int bx)
+{
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.vert_bs) + (long long)f * a.vert_bs_stride, 0, (uint32_t)a.n_vert, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.hor_bs) + (long long)f * a.hor_bs_stride, 0, (uint32_t)a.n_hor, 0x00020000);
+    dbk::BlockBs b;
+    b.ver1 = __builtin_amdgcn_raw_buffer_load_b8(rv, (uint32_t)bx, (by - 1) * a.vstride, 0);
+    b.ver2 = __builtin_amdgcn_raw_buffer_load_b8(rv, (uint32_t)bx, by * a.vstride, 0);
+    b.hor1 = __builtin_amdgcn_raw_buffer_load_b8(rh, (uint32_t)(bx - 1), by * a.hstride, 0); /* bx == 0: 0xffffffff, out of range */
+    b.hor2 = __builtin_amdgcn_raw_buffer_load_b8(rh, bx < a.limit_bx ? (uint32_t)bx : kOob, by * a.hstride, 0);
+    return b;
+}
+
 /* spec-exact mode: the four 4-sample-granular bS bytes of a lane's block (deblock_h265.h load_block_bs_h265); edges on
  * the picture boundary and halves outside the picture read 0 through an out-of-range offset */
 template <int PATH>
@@ -285,7 +302,18 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
      *         out-of-image half is zeroed after the load (the bytes fetched there belong to the neighbouring
      *         image row) and is stored by nobody (split store: full lanes 8 bytes, edge lanes 4).
      * PATH 2: first / last block row: per-lane 4-byte accesses, out-of-image rows and halves via
-     *         out-of-range offsets. */
+     *         out-of-range offsets.
+     * PATH 3: (round 3) the first / last wave of a block row in the row map: by wave-uniform like PATH 0, but the wave
+     *         holds the bx == 0 block (left half outside the image), the bx == nbx-1 block (right half outside) and / or
+     *         idle lanes.  Idle lanes leave at once; everybody else runs PATH 0's memory code against a buffer resource
+     *         whose base lies 4 bytes earlier, so that the bx == 0 lane's 8-byte access has offset 0 instead of -4 (it
+     *         fetches the last 4 bytes of the row above and its own right half); the one or two edge lanes of the wave get
+     *         their outside half zeroed under a wave-uniform guard and store their inside half with a 4-byte access, all
+     *         other lanes with the 8-byte one.  About 25 instructions more than PATH 0 where PATH 1 costs 60: two of the
+     *         eight waves of a 4K block row are such waves. */
+    if constexpr (PATH == 3) {
+        if (!active) return;
+    }
 #ifdef HEVCDBK_DIAG
     /* copy variant, knob "align": every lane moves the naturally aligned 8 bytes 8*bx .. 8*bx+7 (the last block of a row has
      * none), so no 128-byte line is shared between two waves: the seam-free ceiling of the row map (timing only) */
@@ -305,10 +333,11 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
 #endif
     const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h;
 
+    constexpr int kBias = PATH == 3 ? 4 : 0; /* PATH 3: the resource starts 4 bytes before the plane, offsets grow by 4 */
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t *>(a.src) + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
+        const_cast<uint8_t *>(a.src) + (long long)f * a.frame_stride - kBias, 0, plane_bytes + kBias, 0x00020000);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-        a.dst + (long long)f * a.frame_stride, 0, plane_bytes, 0x00020000);
+        a.dst + (long long)f * a.frame_stride - kBias, 0, plane_bytes + kBias, 0x00020000);
 
     uint32_t L[8], R[8];
 #ifdef HEVCDBK_DIAG
@@ -340,6 +369,23 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             L[r] = w.x;
             R[r] = w.y;
         }
+    } else if constexpr (PATH == 3) {
+        const uint32_t xoff3 = (uint32_t)(bx * 8); /* = xoff + kBias */
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff3, (y0 + r) * (int)a.pitch, aux_ld<NT>());
+            L[r] = w.x;
+            R[r] = w.y;
+        }
+        /* the reference's zero padding (cpu.h:55-71) for the one lane of the wave whose half lies outside the image */
+        if (__builtin_amdgcn_ballot_w64(!lv) != 0ull) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) L[r] = lv ? L[r] : 0u;
+        }
+        if (__builtin_amdgcn_ballot_w64(!rv) != 0ull) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) R[r] = rv ? R[r] : 0u;
+        }
     } else if constexpr (PATH == 1) {
         /* the buffer range check looks at the vector offset alone, so it must not go negative: a bx == 0 lane
          * (xoff = -4) fetches its 8 bytes one half further right and takes its right half from the first dword */
@@ -365,7 +411,7 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
     }
 
     if constexpr (MODE == 0 || MODE == 3) { /* 3 = the filter with the timing-only ablation switches compiled in */
-        const dbk::BlockBs bs = load_bs_buffer<PATH != 0>(a, f, by, bx, active);
+        const dbk::BlockBs bs = PATH == 3 ? load_bs_buffer_rowedge(a, f, by, bx) : load_bs_buffer<(PATH != 0)>(a, f, by, bx, active);
         const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
 #ifdef HEVCDBK_DIAG
         if constexpr (MODE == 3) {
@@ -420,6 +466,26 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             w.x = L[r];
             w.y = R[r];
             __builtin_amdgcn_raw_buffer_store_b64(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_st<NT>());
+        }
+    } else if constexpr (PATH == 3) {
+        const uint32_t xoff3 = (uint32_t)(bx * 8);
+        const uint32_t vfull = (lv && rv) ? xoff3 : kOob; /* both halves in the image: the 8-byte store */
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            u32x2 w;
+            w.x = L[r];
+            w.y = R[r];
+            __builtin_amdgcn_raw_buffer_store_b64(w, rd, vfull, (y0 + r) * (int)a.pitch, aux_st<NT>());
+        }
+        if (__builtin_amdgcn_ballot_w64(!lv) != 0ull) { /* the bx == 0 lane: its right half */
+            const uint32_t vh = (!lv && rv) ? xoff3 + 4u : kOob;
+#pragma unroll
+            for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, vh, (y0 + r) * (int)a.pitch, aux_st<NT>());
+        }
+        if (__builtin_amdgcn_ballot_w64(!rv) != 0ull) { /* the bx == nbx-1 lane: its left half */
+            const uint32_t vh = (lv && !rv) ? xoff3 : kOob;
+#pragma unroll
+            for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, vh, (y0 + r) * (int)a.pitch, aux_st<NT>());
         }
     } else if constexpr (PATH == 1) {
         const uint32_t voff = xoff + (uint32_t)((by - by0) * 8) * (uint32_t)a.pitch;
@@ -647,7 +713,7 @@ __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
     if (c.interior) packed_body<CHROMA, MODE, NT, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0);
-    else if (c.rows_in) packed_body<CHROMA, MODE, NT, 1, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0);
+    else if (c.rows_in) packed_body<CHROMA, MODE, NT, LINEAR ? 1 : 3, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0);
     else packed_body<CHROMA, MODE, NT, 2, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0);
 }
 
@@ -659,7 +725,7 @@ __device__ __forceinline__ void packed_h265_dispatch(const DbkH265Args &h)
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
     if (c.interior) packed_body<CHROMA, 2, false, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0, &h);
-    else if (c.rows_in) packed_body<CHROMA, 2, false, 1, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
+    else if (c.rows_in) packed_body<CHROMA, 2, false, LINEAR ? 1 : 3, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
     else packed_body<CHROMA, 2, false, 2, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
 }
 template <bool CHROMA, bool LINEAR, bool QPMAP>
@@ -693,11 +759,11 @@ __global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiAr
     c.interior = wave_bx0 > 0 && wave_bx0 + 64 <= a.nbx - 1 && c.rows_in;
     if (pl == 0) {
         if (c.interior) packed_body<false, 0, NT, 0, false>(a, c.by, c.f, c.bx, true, c.by0);
-        else if (c.rows_in) packed_body<false, 0, NT, 1, false>(a, c.by, c.f, c.bx, c.active, c.by0);
+        else if (c.rows_in) packed_body<false, 0, NT, 3, false>(a, c.by, c.f, c.bx, c.active, c.by0);
         else packed_body<false, 0, NT, 2, false>(a, c.by, c.f, c.bx, c.active, c.by0);
     } else {
         if (c.interior) packed_body<true, 0, NT, 0, false>(a, c.by, c.f, c.bx, true, c.by0);
-        else if (c.rows_in) packed_body<true, 0, NT, 1, false>(a, c.by, c.f, c.bx, c.active, c.by0);
+        else if (c.rows_in) packed_body<true, 0, NT, 3, false>(a, c.by, c.f, c.bx, c.active, c.by0);
         else packed_body<true, 0, NT, 2, false>(a, c.by, c.f, c.bx, c.active, c.by0);
     }
 }
