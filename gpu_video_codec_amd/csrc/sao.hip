@@ -63,18 +63,47 @@ __device__ __forceinline__ void store8(uint8_t *row, int x, const int (&o)[8])
 __device__ __forceinline__ int sgn(int v) { return (v > 0) - (v < 0); }
 
 /*
+ * Workgroup -> (256 x 64 strip, frame).  SWZ: a 1-D grid whose workgroups are renumbered so that each XCD (workgroups are
+ * dealt to the 8 XCDs round-robin -- an observation used for speed only) works through a CONTIGUOUS range of strips,
+ * row-major inside a frame.  The halo of an edge-offset CTB -- the 16-byte row loads reach 4 bytes into the strip to the
+ * left and right, the three-row window one row into the strips above and below -- then lies in lines a neighbouring
+ * workgroup of the SAME XCD fetches as well, i.e. in that XCD's L2, instead of being fetched from HBM once per XCD
+ * (round 2: 1.48 x the plane's bytes read for one third edge CTBs; the same renumbering took the fused deblocking + SAO
+ * kernel from 2.0 x to 1.004 x).  Grids too large for the exact 32-bit reciprocal divisions keep the 3-D numbering.
+ */
+template <bool SWZ>
+__device__ __forceinline__ bool sao_strip(const DbkFusedGrid &g, int &wx, int &wy, int &f)
+{
+    if constexpr (!SWZ) {
+        wx = blockIdx.x; wy = blockIdx.y; f = blockIdx.z;
+        return true;
+    } else {
+        const uint32_t id = blockIdx.x;
+        const uint32_t logical = (id & 7u) * g.per_xcd + (id >> 3);
+        if (logical >= g.total) return false; /* padding workgroup */
+        const uint32_t fr = g.tiles_per_frame == 1u ? logical : __umulhi(logical, g.magic_tpf);
+        const uint32_t in_frame = logical - fr * g.tiles_per_frame;
+        const uint32_t row = g.tiles_x == 1u ? in_frame : __umulhi(in_frame, g.magic_tx);
+        wx = (int)(in_frame - row * g.tiles_x); wy = (int)row; f = (int)fr;
+        return true;
+    }
+}
+
+/*
  * One lane = one 8x8 block of samples (the unit of the keep map; inside one CTB since CTBs are at least 8 samples): the
  * CTB parameters and the keep flag are fetched once, and the edge classifier slides a three-row window down the block, so a
  * row is loaded once per lane (10 rows for 8 rows of output) instead of three times per output row.
  */
-template <typename T>
-__global__ __launch_bounds__(256) void sao_kernel(const DbkSaoArgs a)
+template <typename T, bool SWZ>
+__global__ __launch_bounds__(256) void sao_kernel(const DbkSaoArgs a, const DbkFusedGrid g)
 {
     /* a wave = the 8 x 8 blocks of one 64 x 64 region: with 64-sample CTBs every lane of a wave has the same SAO type and the
      * wave runs ONE of the three paths; a row-shaped wave (512 x 8) would span eight CTBs and run all of them */
+    int wx, wy, f;
+    if (!sao_strip<SWZ>(g, wx, wy, f)) return;
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int x = (blockIdx.x * 4 + wv) * 64 + (l & 7) * 8;
-    const int y0 = blockIdx.y * 64 + (l >> 3) * 8, f = blockIdx.z;
+    const int x = (wx * 4 + wv) * 64 + (l & 7) * 8;
+    const int y0 = wy * 64 + (l >> 3) * 8;
     if (x >= a.plane_w || y0 >= a.plane_h) return;
     const uint8_t *src = a.src + (long long)f * a.frame_stride;
     uint8_t *dst = a.dst + (long long)f * a.frame_stride;
@@ -250,11 +279,14 @@ __device__ __forceinline__ void sao8_edge_block(const DbkSaoArgs &a, const uint8
     }
 }
 
-__global__ __launch_bounds__(256) void sao8_kernel(const DbkSaoArgs a)
+template <bool SWZ>
+__global__ __launch_bounds__(256) void sao8_kernel(const DbkSaoArgs a, const DbkFusedGrid g)
 {
+    int wx, wy, f;
+    if (!sao_strip<SWZ>(g, wx, wy, f)) return;
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int x = (blockIdx.x * 4 + wv) * 64 + (l & 7) * 8;
-    const int y0 = blockIdx.y * 64 + (l >> 3) * 8, f = blockIdx.z;
+    const int x = (wx * 4 + wv) * 64 + (l & 7) * 8;
+    const int y0 = wy * 64 + (l >> 3) * 8;
     if (x >= a.plane_w || y0 >= a.plane_h) return;
     const uint8_t *src = a.src + (long long)f * a.frame_stride;
     uint8_t *dst = a.dst + (long long)f * a.frame_stride;
@@ -298,12 +330,36 @@ __global__ __launch_bounds__(256) void sao8_kernel(const DbkSaoArgs a)
 hipError_t dbk_launch_sao(const DbkSaoArgs &a, int sample_bytes, hipStream_t stream)
 {
     if (a.n_frames <= 0 || a.plane_w <= 0 || a.plane_h <= 0) return hipSuccess;
-    dim3 block(256, 1, 1), grid((a.plane_w + 255) / 256, (a.plane_h + 63) / 64, a.n_frames);
+    const dim3 block(256, 1, 1), grid3((a.plane_w + 255) / 256, (a.plane_h + 63) / 64, a.n_frames);
+    /* the renumbered 1-D grid (sao_strip): strips per frame and in total small enough for exact reciprocal division
+     * (dividend < 2^32 / divisor) */
+    DbkFusedGrid g = {};
+    const unsigned long long tx = grid3.x, tpf = tx * grid3.y, total = tpf * (unsigned long long)a.n_frames;
+    bool swz = total + 8 < (1ull << 31) && (total + 8) * tpf < (1ull << 32) && tpf * tx < (1ull << 32);
+#ifdef HEVCDBK_DIAG
+    if (g_dbk_diag.noswz) swz = false; /* A/B knob of the diagnostic library: the plain 3-D numbering */
+#endif
+    if (swz) {
+        g.tiles_x = (uint32_t)tx;
+        g.tiles_per_frame = (uint32_t)tpf;
+        g.total = (uint32_t)total;
+        g.magic_tpf = tpf <= 1 ? 0u : (uint32_t)((1ull << 32) / tpf + 1ull);
+        g.magic_tx = tx <= 1 ? 0u : (uint32_t)((1ull << 32) / tx + 1ull);
+        g.per_xcd = (uint32_t)((total + 7) / 8);
+    }
+    const dim3 grid = swz ? dim3(g.per_xcd * 8u, 1, 1) : grid3;
     /* 8-bit planes whose rows and frames are 8-byte aligned take the packed kernel (every lane moves 8 bytes at once) */
     const bool aligned8 = a.pitch % 8 == 0 && a.frame_stride % 8 == 0 && ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0 &&
                           a.plane_w % 8 == 0 && a.plane_h % 8 == 0 && a.max_v == 255 && a.band_shift == 3;
-    if (sample_bytes == 1 && aligned8) hipLaunchKernelGGL(sao8_kernel, grid, block, 0, stream, a);
-    else if (sample_bytes == 1) hipLaunchKernelGGL(sao_kernel<uint8_t>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(sao_kernel<uint16_t>, grid, block, 0, stream, a);
+    if (sample_bytes == 1 && aligned8) {
+        if (swz) hipLaunchKernelGGL(sao8_kernel<true>, grid, block, 0, stream, a, g);
+        else hipLaunchKernelGGL(sao8_kernel<false>, grid, block, 0, stream, a, g);
+    } else if (sample_bytes == 1) {
+        if (swz) hipLaunchKernelGGL((sao_kernel<uint8_t, true>), grid, block, 0, stream, a, g);
+        else hipLaunchKernelGGL((sao_kernel<uint8_t, false>), grid, block, 0, stream, a, g);
+    } else {
+        if (swz) hipLaunchKernelGGL((sao_kernel<uint16_t, true>), grid, block, 0, stream, a, g);
+        else hipLaunchKernelGGL((sao_kernel<uint16_t, false>), grid, block, 0, stream, a, g);
+    }
     return hipGetLastError();
 }

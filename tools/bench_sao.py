@@ -15,7 +15,10 @@ def main():
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--types", default="mix", help="mix (one third off / band / edge), off, band, edge: the SAO type of every CTB")
+    ap.add_argument("--diag", default=None, help="run on libhevcdbk_diag.so with these knobs (noswz = the plain 3-D strip numbering)")
     a = ap.parse_args()
+    if a.diag is not None:
+        _lib.use_diagnostic_library(a.diag)
     w, h, n, bd = a.width, a.height, a.frames, a.bit_depth
     sb = 1 if bd == 8 else 2
     ctx = deblock.Context(0)
@@ -43,7 +46,7 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     nbytes = 2 * n * w * h * sb
     print(json.dumps({"stage": "sao", "ms_per_launch": dt * 1e3, "frames_per_s": n / dt, "GBps": nbytes / dt * 1e-9,
-                      "frac_of_8TBps": nbytes / dt / 8e12, "workload": "%dx%d %d-bit luma x %d, CTB types: %s" % (w, h, bd, n, a.types)}))
+                      "frac_of_8TBps": nbytes / dt / 8e12, "workload": "%dx%d %d-bit luma x %d, CTB types: %s" % (w, h, bd, n, a.types), "diag": a.diag}))
 
 
 if __name__ == "__main__":
