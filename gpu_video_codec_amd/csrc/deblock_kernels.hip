@@ -167,6 +167,15 @@ hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, h
 
 namespace {
 
+/*
+ * Every packed kernel declares v63 as touched, so that its waves are allocated exactly 64 VGPRs -- one eighth of a SIMD's
+ * register file -- whatever the register allocator needed (48..63, depending on unrelated details of the source).  Measured
+ * in round 3 (profiles/r03/experiments.md): the same kernel at 48 VGPRs runs 1 % SLOWER than at 63, with 17 % fewer waves
+ * resident on average (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES): a SIMD has 8 wave slots either way, and with allocations that do
+ * not tile the file, a finished wave's registers are not always where the next wave fits.
+ */
+#define DBK_WHOLE_SLOT() asm volatile("" ::: "v63")
+
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -399,14 +408,18 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             R[r] = rv ? (lv ? w.y : w.x) : 0u;
         }
     } else {
-        /* straight-line, per-lane offsets: an out-of-image half or row gets an out-of-range offset (load -> 0) */
+        /* straight-line, per-lane offsets: an out-of-image half or row gets an out-of-range offset (load -> 0).  The offset is
+         * pushed out of range by OR-ing kOob into it -- a per-lane word for the halves, a scalar word per row -- instead of
+         * selecting under sixteen 64-bit lane masks: those masks made this path, which runs in two block rows of a frame, the
+         * SGPR peak of the whole kernel */
         const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
+        const uint32_t lbits = lv ? 0u : kOob, rbits = rv ? 0u : kOob;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
+            const uint32_t ob = (unsigned)(y0 + r) < (unsigned)a.plane_h ? 0u : kOob; /* scalar */
             const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
-            L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && lv) ? off : kOob, 0, aux_ld<NT>());
-            R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yv && rv) ? off + 4u : kOob, 0, aux_ld<NT>());
+            L[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, off | lbits | ob, 0, aux_ld<NT>());
+            R[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (off + 4u) | rbits | ob, 0, aux_ld<NT>());
         }
     }
 
@@ -420,12 +433,12 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             for (int i = 0; i < a.diag_dummy; i++) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(sink) : "v"(R[0]));
             if (a.diag_dummy && sink == 0x12345678u) L[0] ^= 1u; /* keeps the chain alive; never true for packed samples */
         }
-        dbk::packed_filter_block<CHROMA>(L, R, bs, q, MODE == 3 ? a.diag_ablate : 0);
+        dbk::packed_filter_block<CHROMA, !QPMAP>(L, R, bs, q, MODE == 3 ? a.diag_ablate : 0);
         if constexpr (MODE == 3) {
             if (a.diag_prio & 2) __builtin_amdgcn_s_setprio(3);
         }
 #else
-        dbk::packed_filter_block<CHROMA>(L, R, bs, q);
+        dbk::packed_filter_block<CHROMA, !QPMAP>(L, R, bs, q);
 #endif
     }
 #ifdef HEVCDBK_DIAG
@@ -456,16 +469,28 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
                 sg.tc[i] = (entry[i] & dbk::kH265BsMask) == 2 ? hx->tc_bs2 : hx->tc_bs1;
             }
         }
-        dbk::packed_filter_block_h265<CHROMA>(L, R, sg);
+        if constexpr (!QPMAP && !CHROMA) { /* the segment constants of both bS values, once per block, on the scalar unit */
+            const dbk::H265Uni u = dbk::h265_uni(hx->beta_s, hx->tc_bs1, hx->tc_bs2);
+            dbk::packed_filter_block_h265<CHROMA>(L, R, sg, &u);
+        } else {
+            dbk::packed_filter_block_h265<CHROMA>(L, R, sg);
+        }
     }
 
+    /* the eight scalar row offsets are built AGAIN for the stores (the empty asm hides from the compiler that they equal the
+     * loads' offsets): carried across the filter they cost 8 SGPRs, and the kernel's SGPR allocation decides how many waves
+     * really fit a SIMD -- 800 SGPRs per SIMD in blocks of 16: at 80 per wave ten waves' worth fit and eight always find room,
+     * at 96 only 8.3 do and a finished wave's block is not always where the next wave's fits (round 3: the same
+     * instructions at 93 instead of 78 SGPRs ran 1 % slower with 17 % fewer waves resident on average) */
+    int spitch = __builtin_amdgcn_readfirstlane((int)a.pitch); /* wave-uniform by construction; says so to the compiler */
+    asm volatile("" : "+s"(spitch));
     if constexpr (PATH == 0) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             u32x2 w;
             w.x = L[r];
             w.y = R[r];
-            __builtin_amdgcn_raw_buffer_store_b64(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_st<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(w, rd, xoff, (y0 + r) * spitch, aux_st<NT>());
         }
     } else if constexpr (PATH == 3) {
         const uint32_t xoff3 = (uint32_t)(bx * 8);
@@ -475,17 +500,17 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             u32x2 w;
             w.x = L[r];
             w.y = R[r];
-            __builtin_amdgcn_raw_buffer_store_b64(w, rd, vfull, (y0 + r) * (int)a.pitch, aux_st<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(w, rd, vfull, (y0 + r) * spitch, aux_st<NT>());
         }
         if (__builtin_amdgcn_ballot_w64(!lv) != 0ull) { /* the bx == 0 lane: its right half */
             const uint32_t vh = (!lv && rv) ? xoff3 + 4u : kOob;
 #pragma unroll
-            for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, vh, (y0 + r) * (int)a.pitch, aux_st<NT>());
+            for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, vh, (y0 + r) * spitch, aux_st<NT>());
         }
         if (__builtin_amdgcn_ballot_w64(!rv) != 0ull) { /* the bx == nbx-1 lane: its left half */
             const uint32_t vh = (lv && !rv) ? xoff3 : kOob;
 #pragma unroll
-            for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, vh, (y0 + r) * (int)a.pitch, aux_st<NT>());
+            for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, vh, (y0 + r) * spitch, aux_st<NT>());
         }
     } else if constexpr (PATH == 1) {
         const uint32_t voff = xoff + (uint32_t)((by - by0) * 8) * (uint32_t)a.pitch;
@@ -501,13 +526,18 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             __builtin_amdgcn_raw_buffer_store_b32(lv ? L[r] : R[r], rd, vhalf, (y0s + r) * (int)a.pitch, aux_st<NT>());
         }
     } else {
-        const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
+        /* the 16 per-lane offsets are built AGAIN here (the empty asm keeps the compiler from carrying the load offsets across
+         * the whole filter): this path runs in the first and last block row only, but its 16 live address registers set the
+         * VGPR count -- and with it the waves per SIMD -- of the entire kernel */
+        uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
+        asm volatile("" : "+v"(base));
+        const uint32_t lbits = lv ? 0u : kOob, rbits = rv ? 0u : kOob;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
+            const uint32_t ob = (unsigned)(y0 + r) < (unsigned)a.plane_h ? 0u : kOob;
             const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
-            __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, (yv && lv) ? off : kOob, 0, aux_st<NT>());
-            __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, (yv && rv) ? off + 4u : kOob, 0, aux_st<NT>());
+            __builtin_amdgcn_raw_buffer_store_b32(L[r], rd, off | lbits | ob, 0, aux_st<NT>());
+            __builtin_amdgcn_raw_buffer_store_b32(R[r], rd, (off + 4u) | rbits | ob, 0, aux_st<NT>());
         }
     }
 }
@@ -548,13 +578,15 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
             W[r][0] = w.x; W[r][1] = w.y; W[r][2] = w.z; W[r][3] = w.w;
         }
     } else {
+        /* out-of-image halves / rows: kOob OR-ed into the offset (packed_body, PATH 2) */
         const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
+        const uint32_t lbits = lv ? 0u : kOob, rbits = rv ? 0u : kOob;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
+            const uint32_t ob = (unsigned)(y0 + r) < (unsigned)a.plane_h ? 0u : kOob;
             const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
-            const u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(rs, (yv && lv) ? off : kOob, 0, aux_ld<NT>());
-            const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rs, (yv && rv) ? off + 8u : kOob, 0, aux_ld<NT>());
+            const u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(rs, off | lbits | ob, 0, aux_ld<NT>());
+            const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rs, (off + 8u) | rbits | ob, 0, aux_ld<NT>());
             W[r][0] = l.x; W[r][1] = l.y; W[r][2] = rr.x; W[r][3] = rr.y;
         }
     }
@@ -563,7 +595,7 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
         const dbk::BlockBs bs = load_bs_buffer<EDGE>(a, f, by, bx, active);
         const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
         if constexpr (CHROMA) dbk::packed_filter_chroma_block16(W, bs, q, a.max_v);
-        else dbk::packed_filter_luma_block16<WIDE>(W, bs, q, a.max_v);
+        else dbk::packed_filter_luma_block16<WIDE, !QPMAP>(W, bs, q, a.max_v);
     } else if constexpr (MODE == 2) { /* spec-exact mode, H.265 8.7.2 */
         int entry[4];
         load_bs_buffer_h265<EDGE ? 2 : 0>(a, f, by, bx, active, entry);
@@ -583,7 +615,12 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
                 sg.tc[i] = (entry[i] & dbk::kH265BsMask) == 2 ? hx->tc_bs2 : hx->tc_bs1;
             }
         }
-        dbk::packed_filter_block16_h265<CHROMA, WIDE>(W, sg, a.max_v);
+        if constexpr (!QPMAP && !CHROMA) {
+            const dbk::H265Uni u = dbk::h265_uni(hx->beta_s, hx->tc_bs1, hx->tc_bs2);
+            dbk::packed_filter_block16_h265<CHROMA, WIDE>(W, sg, a.max_v, &u);
+        } else {
+            dbk::packed_filter_block16_h265<CHROMA, WIDE>(W, sg, a.max_v);
+        }
     }
 
     if constexpr (!EDGE) {
@@ -594,15 +631,17 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
             __builtin_amdgcn_raw_buffer_store_b128(w, rd, xoff, (y0 + r) * (int)a.pitch, aux_st<NT>());
         }
     } else {
-        const uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
+        uint32_t base = (uint32_t)(y0 * (int)a.pitch) + xoff;
+        asm volatile("" : "+v"(base)); /* rebuild the 16 offsets here instead of carrying them across the filter (packed_body, PATH 2) */
+        const uint32_t lbits = lv ? 0u : kOob, rbits = rv ? 0u : kOob;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const bool yv = (unsigned)(y0 + r) < (unsigned)a.plane_h;
+            const uint32_t ob = (unsigned)(y0 + r) < (unsigned)a.plane_h ? 0u : kOob;
             const uint32_t off = base + (uint32_t)r * (uint32_t)a.pitch;
             u32x2 l, rr;
             l.x = W[r][0]; l.y = W[r][1]; rr.x = W[r][2]; rr.y = W[r][3];
-            __builtin_amdgcn_raw_buffer_store_b64(l, rd, (yv && lv) ? off : kOob, 0, aux_st<NT>());
-            __builtin_amdgcn_raw_buffer_store_b64(rr, rd, (yv && rv) ? off + 8u : kOob, 0, aux_st<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(l, rd, off | lbits | ob, 0, aux_st<NT>());
+            __builtin_amdgcn_raw_buffer_store_b64(rr, rd, (off + 8u) | rbits | ob, 0, aux_st<NT>());
         }
     }
 }
@@ -673,6 +712,7 @@ __device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
 template <int MODE, bool NT, bool LINEAR, bool QPMAP, bool WIDE = false>
 __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
 {
+    DBK_WHOLE_SLOT();
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
     if (c.interior) packed16_body<MODE, NT, false, QPMAP, false, WIDE>(a, c.by, c.f, c.bx, true);
@@ -683,6 +723,7 @@ __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
 template <bool LINEAR, bool QPMAP>
 __global__ __launch_bounds__(1024) void dbk_packed16c_kernel(const DbkArgs a)
 {
+    DBK_WHOLE_SLOT();
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
     if (c.interior) packed16_body<0, false, false, QPMAP, true>(a, c.by, c.f, c.bx, true);
@@ -691,6 +732,7 @@ __global__ __launch_bounds__(1024) void dbk_packed16c_kernel(const DbkArgs a)
 template <bool CHROMA, bool LINEAR, bool QPMAP, bool WIDE = false>
 __global__ __launch_bounds__(1024) void dbk_packed16_h265_kernel(const DbkH265Args h)
 {
+    DBK_WHOLE_SLOT();
     const DbkArgs &a = h.base;
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
@@ -710,6 +752,7 @@ __global__ __launch_bounds__(1024) void dbk_packed16_h265_kernel(const DbkH265Ar
 template <bool CHROMA, int MODE, bool NT, bool LINEAR, bool QPMAP>
 __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
 {
+    DBK_WHOLE_SLOT();
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
     if (c.interior) packed_body<CHROMA, MODE, NT, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0);
@@ -731,6 +774,7 @@ __device__ __forceinline__ void packed_h265_dispatch(const DbkH265Args &h)
 template <bool CHROMA, bool LINEAR, bool QPMAP>
 __global__ __launch_bounds__(1024) void dbk_packed_h265_kernel(const DbkH265Args h)
 {
+    DBK_WHOLE_SLOT();
     packed_h265_dispatch<CHROMA, LINEAR, QPMAP>(h);
 }
 /* ------------------------------------------------------------------------------------------ */
@@ -744,6 +788,7 @@ __global__ __launch_bounds__(1024) void dbk_packed_h265_kernel(const DbkH265Args
 template <bool NT>
 __global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiArgs m)
 {
+    DBK_WHOLE_SLOT();
     const int row = blockIdx.x;
     const int pl = row >= m.row_end[0] ? (row >= m.row_end[1] ? 2 : 1) : 0; /* scalar */
     const DbkArgs &a = m.p[pl];
@@ -774,6 +819,7 @@ __global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiAr
 template <bool WIDE>
 __global__ __launch_bounds__(1024) void dbk_packed16_multi_kernel(const DbkMultiArgs m)
 {
+    DBK_WHOLE_SLOT();
     const int row = blockIdx.x;
     const int pl = row >= m.row_end[0] ? (row >= m.row_end[1] ? 2 : 1) : 0; /* scalar */
     const DbkArgs &a = m.p[pl];

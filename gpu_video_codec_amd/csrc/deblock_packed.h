@@ -216,35 +216,112 @@ struct Decision {
 };
 
 /*
+ * Everything a luma segment needs that depends on (beta, tc) and the filter mode only, behind one interface with two
+ * shapes:
+ *   LumaKLazy  -- wave-uniform beta / tc (one QP per launch; the spec-exact mode's uniform waves): holds the two scalars and
+ *                 derives each operand where it is used, with a handful of scalar instructions.  Nothing but beta and tc
+ *                 stays live across a segment: measured in round 3, the same instruction stream with all operands built at
+ *                 the top of the segment needs 93 instead of 78 SGPRs and runs 1-2 % slower -- 800 SGPRs per SIMD are
+ *                 handed out in blocks of 16, eight waves of 96 fill them to the brim and a new wave does not always find
+ *                 its block free (17 % fewer waves resident on average, SQ_WAVE_CYCLES / SQ_BUSY_CYCLES);
+ *   LumaKEager -- per-lane beta / tc (per-CTU QP map): the operands are vector registers, built once per segment.
+ * H265 == false: the reference's filter (cpu.h);  H265 == true: the standard's (8.7.2.5.3 / .6 / .7) -- they differ in
+ * the three thresholds of the strong decision, in the cond5 / cond6 threshold and in the clip of the normal delta.
+ */
+template <bool H265 = false>
+struct LumaKLazy {
+    int beta, tc;
+    /* decisions.  reference: d(P,i)+d(Q,i) < beta/8, |p3-p0|+|q0-q3| < beta/8, |p0-q0| < 5*tc/2 (cpu.h:1099-1110);
+     * standard: 2*(d(P,i)+d(Q,i)) < beta>>2, i.e. d < ceil((beta>>2)/2); ... < beta>>3; |p0-q0| < (5*tc+1)>>1 */
+    DBK_HD int t_dpq() const { return H265 ? ((beta >> 2) + 1) >> 1 : beta >> 3; }
+    DBK_HD int t_e() const { return beta >> 3; }
+    DBK_HD int t_f() const { return H265 ? (5 * tc + 1) >> 1 : (5 * tc) >> 1; }
+    DBK_HD uint32_t filter_thr() const { return (uint32_t)beta + 4u; }                            /* cpu.h:1086-1087; the field is d + 4 */
+    /* biases in both halves: field + bias has bit 15 set <=> field >= its threshold */
+    DBK_HD uint32_t km_dpq() const { return (uint32_t)(0x8000 - t_dpq() - 2) * 0x00010001u; }     /* the field is d + 2 */
+    DBK_HD uint32_t km_e() const { return (uint32_t)(0x8000 - t_e()) * 0x00010001u; }
+    DBK_HD uint32_t kf() const { return (uint32_t)(0x8000 - t_f()) * 0x00010001u; }
+    DBK_HD bool strong_possible() const { return t_dpq() > 0 && t_e() > 0 && t_f() > 0; }
+    DBK_HD uint32_t side_thr() const { return (uint32_t)(H265 ? (beta + (beta >> 1)) >> 3 : (3 * beta) >> 4) + 2u; } /* cpu.h:1243-1249, + 2 */
+    /* strong filter: clip range c = 2*tc */
+    DBK_HD uint32_t c16() const { return (uint32_t)(2 * tc) & 0xffffu; }
+    DBK_HD pk sc2() const { return bits_pk((2u * c16()) * 0x00010001u); }
+    DBK_HD uint32_t snegc() const { return 0u - c16() * 0x00010001u; }
+    DBK_HD pk sk() const { return bits_pk((4u * c16() + 2u) * 0x00010001u); }                     /* 2 + 4c: carries the + c */
+    /* normal filter: clip of delta 2*tc (reference, cpu.h:1256) / tc (standard); tc/2; 10*tc */
+    DBK_HD int ncv() const { return H265 ? tc : 2 * tc; }
+    DBK_HD pk nc() const { return splat_u(ncv()); }
+    DBK_HD pk nnegc() const { return splat_u(-ncv()); }
+    DBK_HD pk nc2() const { return splat_u(tc >> 1); }
+    DBK_HD pk nnegc2() const { return splat_u(-(tc >> 1)); }
+    DBK_HD pk nlim() const { return splat_u(10 * tc); }
+    /* largest power of two <= 10*tc in both halves, and the bits at or above twice that */
+    DBK_HD uint32_t p2() const { return tc > 0 ? 1u << (31 - __builtin_clz((unsigned)(10 * tc))) : 1u; }
+    DBK_HD uint32_t nP() const { return p2() * 0x00010001u; }
+    DBK_HD uint32_t nmask() const { return 0x00010001u * (0xffffu & ~(2u * p2() - 1u)); }
+    DBK_HD bool tc_zero() const { return tc <= 0; }
+};
+struct LumaKEager {
+    uint32_t filter_thr_, km_dpq_, km_e_, kf_, side_thr_, snegc_, nP_, nmask_;
+    bool strong_possible_, tc_zero_;
+    pk sc2_, sk_, nc_, nnegc_, nc2_, nnegc2_, nlim_;
+    template <bool H265>
+    DBK_HD static LumaKEager make(int beta, int tc)
+    {
+        const LumaKLazy<H265> z{beta, tc};
+        LumaKEager k;
+        k.filter_thr_ = z.filter_thr(); k.km_dpq_ = z.km_dpq(); k.km_e_ = z.km_e(); k.kf_ = z.kf(); k.side_thr_ = z.side_thr();
+        k.snegc_ = z.snegc(); k.nP_ = z.nP(); k.nmask_ = z.nmask(); k.strong_possible_ = z.strong_possible(); k.tc_zero_ = z.tc_zero();
+        k.sc2_ = z.sc2(); k.sk_ = z.sk(); k.nc_ = z.nc(); k.nnegc_ = z.nnegc(); k.nc2_ = z.nc2(); k.nnegc2_ = z.nnegc2(); k.nlim_ = z.nlim();
+        return k;
+    }
+    DBK_HD uint32_t filter_thr() const { return filter_thr_; }
+    DBK_HD uint32_t km_dpq() const { return km_dpq_; }
+    DBK_HD uint32_t km_e() const { return km_e_; }
+    DBK_HD uint32_t kf() const { return kf_; }
+    DBK_HD bool strong_possible() const { return strong_possible_; }
+    DBK_HD uint32_t side_thr() const { return side_thr_; }
+    DBK_HD pk sc2() const { return sc2_; }
+    DBK_HD uint32_t snegc() const { return snegc_; }
+    DBK_HD pk sk() const { return sk_; }
+    DBK_HD pk nc() const { return nc_; }
+    DBK_HD pk nnegc() const { return nnegc_; }
+    DBK_HD pk nc2() const { return nc2_; }
+    DBK_HD pk nnegc2() const { return nnegc2_; }
+    DBK_HD pk nlim() const { return nlim_; }
+    DBK_HD uint32_t nP() const { return nP_; }
+    DBK_HD uint32_t nmask() const { return nmask_; }
+    DBK_HD bool tc_zero() const { return tc_zero_; }
+};
+
+/*
  * Round 3 form.  Everything carries a small constant so that no instruction exists only to add one:
  *   tp1 = p2 + p0 + 1 - 2*p1 (the "+ 1" is the rounding term of the normal filter's p1 update, cpu.h:1281, and rides in the
  *         three-operand add that forms p2 + p0);  |tp| + 1 = max(tp1, 2 - tp1)  -- still two instructions;
  *   every threshold the +1 / +2 reaches is a wave-uniform scalar and moves with it.
  * |a - b| of unsigned fields = (a -sat b) + (b -sat a) (one of the two is 0): the two saturating subtractions replace
  * max / min / sub, and the sum rides in the three-operand add that follows anyway.
- * "field < T" tests: field + (0x8000 - T) has bit 15 set iff field >= T; the bias rides in the same adds.
+ * "field < T" tests: field + (0x8000 - T) has bit 15 set iff field >= T; the bias rides in the same adds, and the biased
+ * fields of the two tests that share... nothing but the mask are merged by an UNSIGNED packed max.
  */
-DBK_HD Decision decide(const Taps &a, int beta, int tc)
+template <class K>
+DBK_HD Decision decide(const Taps &a, const K &k)
 {
     Decision d;
     const pk tp1 = mad_k<-2>(a.p1, uadd3c(a.p2, a.p0, 0x00010001u)), tq1 = mad_k<-2>(a.q1, uadd3c(a.q2, a.q0, 0x00010001u));
     const pk dp1 = pk_max(tp1, splat(2) - tp1), dq1 = pk_max(tq1, splat(2) - tq1); /* |.| + 1 on lines 0 and 3 */
     d.tp1 = tp1;
     d.tq1 = tq1;
-    const pk dpq2 = uadd(dp1, dq1);                                   /* d(P,i) + d(Q,i) + 2 */
     /* sum of the two halves in the low 16 bits: x + (x >> 16), compared as a 16-bit value */
-    d.filter = lohi_sum(dpq2) < (unsigned)beta + 4u;                  /* cpu.h:1086-1087 */
-    const int b8 = beta >> 3, tc52 = (5 * tc) >> 1;                   /* beta/8, 5*tc/2: non-negative => >> is / */
-    /* cpu.h:1104-1105: |p3 - p0| + |q0 - q3| (+ 2, to sit beside dpq2) */
-    const pk e2 = uadd3c(uadd3(sub_sat(a.p3, a.p0), sub_sat(a.p0, a.p3), sub_sat(a.q0, a.q3)), sub_sat(a.q3, a.q0), 0x00020002u);
-    const pk m2 = pk_max(dpq2, e2);                                   /* both tested against beta/8 */
-    const uint32_t km = (uint32_t)(0x8000 - b8 - 2) * 0x00010001u, kf = (uint32_t)(0x8000 - tc52) * 0x00010001u;
-    /* bit 15 of a half set <=> that line violates a strong-filter condition (cpu.h:1099-1110) */
-    const uint32_t bad = or_and(pk_bits(uaddc(m2, km)), pk_bits(uadd3c(sub_sat(a.p0, a.q0), sub_sat(a.q0, a.p0), kf)), 0x80008000u);
-    d.strong = b8 > 0 && tc52 > 0 && bad == 0u;
-    const unsigned b316 = (unsigned)((3 * beta) >> 4) + 2u;           /* 3*beta/16 (+ 2: the fields are |.| + 1) */
-    d.cond5 = lohi_sum(dp1) < b316;
-    d.cond6 = lohi_sum(dq1) < b316;
+    d.filter = lohi_sum(uadd(dp1, dq1)) < k.filter_thr();
+    const pk dpqk = uadd3c(dp1, dq1, k.km_dpq());                        /* d(P,i) + d(Q,i), biased */
+    const pk ek = uadd3c(uadd3(sub_sat(a.p3, a.p0), sub_sat(a.p0, a.p3), sub_sat(a.q0, a.q3)), sub_sat(a.q3, a.q0), k.km_e());
+    const pk fk = uadd3c(sub_sat(a.p0, a.q0), sub_sat(a.q0, a.p0), k.kf());
+    /* bit 15 of a half set <=> that line violates a strong-filter condition */
+    const uint32_t bad = or_and(pk_bits(pk_maxu(dpqk, ek)), pk_bits(fk), 0x80008000u);
+    d.strong = k.strong_possible() && bad == 0u;
+    d.cond5 = lohi_sum(dp1) < k.side_thr();
+    d.cond6 = lohi_sum(dq1) < k.side_thr();
     return d;
 }
 
@@ -271,12 +348,11 @@ DBK_HD pk shr_sum(pk x)
  * wave-uniform operands, and p + x - c is one three-operand add on the packed register: both fields of p + x are >= c (x = 0
  * only where s < p - c, i.e. p > c, because s >= 0), so no borrow crosses the field boundary.  Three instructions per output
  * (round 1-2: max, add, min, sub).  All fields stay non-negative and below 2^15 (8*max_v + 4 + 8c; WIDE: below 2^16). */
-template <bool WIDE = false>
-DBK_HD void strong_pair(Taps &t, pk c)
+template <bool WIDE = false, bool UNI = true, class K>
+DBK_HD void strong_pair(Taps &t, const K &lk)
 {
-    const pk k = uaddc(uadd(uadd(c, c), uadd(c, c)), 0x00020002u); /* 2 + 4c */
-    const pk c2 = uadd(c, c);
-    const uint32_t negc = 0u - pk_bits(c);
+    const pk k = lk.sk(), c2 = lk.sc2();
+    const uint32_t negc = lk.snegc();
     const pk u2 = uadd(uadd(t.p0, t.q0), k);
     const pk tp = uadd(u2, t.p1);       /* p1+p0+q0+2 (+4c) */
     const pk tq = uadd(u2, t.q1);
@@ -289,12 +365,16 @@ DBK_HD void strong_pair(Taps &t, pk c)
     const pk s0q = shr_sum<WIDE, 3>(uadd(uadd(tq, bq), t.p1));
     const pk s1q = shr_sum<WIDE, 2>(bq);
     const pk s2q = shr_sum<WIDE, 3>(uadd(uadd(uadd(q32, q32), bq), k));
-    /* hipcc splits p + x + negc into (p - c) + x, two instructions: the three-operand add is written out */
+    /* hipcc splits p + x + negc into (p - c) + x, two instructions: the three-operand add is written out.  UNI: -c is
+     * wave-uniform and sits in an SGPR; otherwise (per-CTU QP map, per-lane bS in the spec-exact mode) it is a vector
+     * register -- an "s" constraint on a divergent value would let a toolchain legalise it with v_readfirstlane and use
+     * lane 0's tc for every lane */
     auto fin = [&](pk s, pk p) {
         const pk x = pk_min(sub_sat(s, p), c2);
 #if DBK_DEV
         uint32_t d;
-        asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(pk_bits(p)), "v"(pk_bits(x)), "s"(negc));
+        if constexpr (UNI) asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(pk_bits(p)), "v"(pk_bits(x)), "s"(negc));
+        else asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(pk_bits(p)), "v"(pk_bits(x)), "v"(negc));
         return bits_pk(d);
 #else
         return bits_pk(pk_bits(p) + pk_bits(x) + negc);
@@ -304,21 +384,6 @@ DBK_HD void strong_pair(Taps &t, pk c)
     const pk nq0 = fin(s0q, t.q0), nq1 = fin(s1q, t.q1), nq2 = fin(s2q, t.q2);
     t.p0 = np0; t.p1 = np1; t.p2 = np2;
     t.q0 = nq0; t.q1 = nq1; t.q2 = nq2;
-}
-
-/* operands of the normal filter that depend on tc only (cpu.h:1233-1236, 1254): built once per segment */
-struct NormalK {
-    pk c, negc;   /* 2*tc and its negation */
-    pk c2, negc2; /* tc/2 */
-    pk lim;       /* 10*tc */
-};
-DBK_HD NormalK normal_k(int tc)
-{
-    NormalK k;
-    k.c = splat_u(2 * tc); k.negc = splat_u(-2 * tc);
-    k.c2 = splat_u(tc >> 1); k.negc2 = splat_u(-(tc >> 1));
-    k.lim = splat_u(10 * tc);
-    return k;
 }
 
 /* (9(q0-p0) - 3(q1-p1) + 8) >> 4 (cpu.h:1253) as two multiply-adds (v_pk_mad_i16) */
@@ -342,11 +407,11 @@ DBK_HD pk normal_delta(const Taps &t)
 struct NormalD {
     pk D, dp1, dq1;
 };
-template <bool ALL_ON, bool HAVE_T = false>
-DBK_HD NormalD normal_deltas(const Taps &t, pk delta, const NormalK &k, pk tp = pk{0, 0}, pk tq = pk{0, 0})
+template <bool ALL_ON, bool HAVE_T = false, class K>
+DBK_HD NormalD normal_deltas(const Taps &t, pk delta, const K &k, pk tp = pk{0, 0}, pk tq = pk{0, 0})
 {
     NormalD n;
-    n.D = pk_min(pk_max(delta, k.negc), k.c);
+    n.D = pk_min(pk_max(delta, k.nnegc()), k.nc());
     /* (((p2+p0+1)>>1) - p1 + D) >> 1  ==  (p2 + p0 + 1 - 2*p1 + 2*D) >> 2   (floor of a floor: the dropped
      * bit of the inner shift is worth 1/4 and cannot carry across an integer).  HAVE_T: p2 + p0 + 1 - 2*p1 (and the Q twin)
      * of this pair is already there from the decisions (pair A) */
@@ -358,10 +423,10 @@ DBK_HD NormalD normal_deltas(const Taps &t, pk delta, const NormalK &k, pk tp = 
         ip = mad_k<-2>(t.p1, uadd3c(t.p2, t.p0, 0x00010001u));
         iq = mad_k<-2>(t.q1, uadd3c(t.q2, t.q0, 0x00010001u));
     }
-    n.dp1 = pk_min(pk_max(mad_k<2>(n.D, ip) >> 2, k.negc2), k.c2);
-    n.dq1 = pk_min(pk_max(mad_k<-2>(n.D, iq) >> 2, k.negc2), k.c2);
+    n.dp1 = pk_min(pk_max(mad_k<2>(n.D, ip) >> 2, k.nnegc2()), k.nc2());
+    n.dq1 = pk_min(pk_max(mad_k<-2>(n.D, iq) >> 2, k.nnegc2()), k.nc2());
     if constexpr (!ALL_ON) {
-        const pk on = (pk_abs(delta) - k.lim) >> 15; /* all ones where |delta| < 10*tc (cpu.h:1254) */
+        const pk on = (pk_abs(delta) - k.nlim()) >> 15; /* all ones where |delta| < 10*tc (cpu.h:1254) */
         n.D = n.D & on;
         n.dp1 = n.dp1 & on;
         n.dq1 = n.dq1 & on;
@@ -389,31 +454,39 @@ DBK_HD bool any_lane(bool v)
 #endif
 }
 
+/* the lanes of the wave that say yes, as a mask (CPU build: this block's own answer in bit 0) */
+DBK_HD unsigned long long lane_ballot(bool v)
+{
+#if DBK_DEV
+    return __builtin_amdgcn_ballot_w64(v);
+#else
+    return v ? 1ull : 0ull;
+#endif
+}
+
 /* both pairs of a normal-filtered segment.  The final Clip2 (cpu.h:1268-1275) only ever acts on samples
  * within 2*tc of 0 or max_v; one OR over the eight results shows whether any field left [0, max_v]
  * (a negative field has its top bits set, a too-large one has a bit above max_v), and the 16
  * min/max instructions run only in waves where some lane needs them.  Likewise the |delta| < 10*tc switch of a line
  * (cpu.h:1254): a line fails it only across a real picture edge, so the per-line masks are built only in waves where
  * some lane has such a line. */
-template <bool WIDE = false, bool HAVE_T = false>
-DBK_HD void normal_pairs(Taps &a, Taps &b, int tc, pk m5, pk m6, int max_v, pk tp = pk{0, 0}, pk tq = pk{0, 0})
+template <bool WIDE = false, bool HAVE_T = false, class K>
+DBK_HD void normal_pairs(Taps &a, Taps &b, const K &k, pk m5, pk m6, int max_v, pk tp = pk{0, 0}, pk tq = pk{0, 0})
 {
-    const NormalK k = normal_k(tc);
     const pk da = normal_delta<WIDE>(a), db = normal_delta<WIDE>(b);
     /* One test for the four lines of the segment, and a conservative one: with P the largest power of two <= 10*tc,
      * |delta| < P in every line <=> (delta + P) has no bit at or above 2P in any half -- two adds, one OR-AND, one compare
      * (round 2: the exact test per pair, 3 + 3).  A wave in which some line has P <= |delta| takes the masked form, which is
      * exact for every line; on picture content |delta| >= 10*tc/2 happens across real edges only.  The wave-uniform tc == 0
      * case joins the ballot as a scalar OR. */
-    const uint32_t P = tc > 0 ? 1u << (31 - __builtin_clz((unsigned)(10 * tc))) : 1u;
-    const uint32_t wide = or_and(pk_bits(da + bits_pk(P * 0x00010001u)), pk_bits(db + bits_pk(P * 0x00010001u)), 0x00010001u * (0xffffu & ~(2u * P - 1u)));
+    const uint32_t wide = or_and(pk_bits(da + bits_pk(k.nP())), pk_bits(db + bits_pk(k.nP())), k.nmask());
     NormalD na, nb;
-    if (tc <= 0 || any_lane(wide != 0u)) {
+    if (__builtin_expect(any_lane(k.tc_zero() || wide != 0u), 0)) {
         na = normal_deltas<false, HAVE_T>(a, da, k, tp, tq);
-        nb = normal_deltas<false>(b, db, k);
+        nb = normal_deltas<false, false>(b, db, k);
     } else {
         na = normal_deltas<true, HAVE_T>(a, da, k, tp, tq);
-        nb = normal_deltas<true>(b, db, k);
+        nb = normal_deltas<true, false>(b, db, k);
     }
     normal_update(a, na, m5, m6); /* the updates themselves: once, behind the join */
     normal_update(b, nb, m5, m6);
@@ -432,17 +505,16 @@ DBK_HD void normal_pairs(Taps &a, Taps &b, int tc, pk m5, pk m6, int max_v, pk t
 /* one luma segment given its two unpacked pairs; returns false when nothing changed */
 /* ablate (diagnostic builds of the benchmark only, 0 in the product): 1 = treat strong segments as
  * normal, 2 = skip the normal filter -- wrong pixels, used to price each path on the GPU */
-template <bool WIDE = false>
-DBK_HD bool luma_pairs(Taps &a, Taps &b, int beta, int tc, int max_v = 255, int ablate = 0)
+template <bool WIDE = false, bool UNI = true, class K>
+DBK_HD bool luma_pairs(Taps &a, Taps &b, const K &k, int max_v = 255, int ablate = 0)
 {
-    const Decision d = decide(a, beta, tc);
+    const Decision d = decide(a, k);
     if (!d.filter) return false;
     if (d.strong && ablate != 1) {
-        const pk c = splat(2 * tc);
-        strong_pair<WIDE>(a, c);
-        strong_pair<WIDE>(b, c);
+        strong_pair<WIDE, UNI>(a, k);
+        strong_pair<WIDE, UNI>(b, k);
     } else if (ablate != 2) {
-        normal_pairs<WIDE, true>(a, b, tc, one_of(d.cond5), one_of(d.cond6), max_v, d.tp1, d.tq1);
+        normal_pairs<WIDE, true>(a, b, k, one_of(d.cond5), one_of(d.cond6), max_v, d.tp1, d.tq1);
     }
     return true;
 }
@@ -521,12 +593,22 @@ DBK_HD void diag_barriers(int ablate)
 /* the four segments on already-unpacked ver registers; leaves the final values in
  * ha/hb (cols 0..3 of rows 0..3 as P, taps p3..p0), ga/gb (P = cols 4..7 of rows 0..3, Q = cols 0..3 of
  * rows 4..7) and va2/vb2 q taps (cols 4..7 of rows 4..7) */
-template <bool WIDE = false>
+/* one reference-exact luma segment from its tc / beta: wave-uniform values take the lazy operand set, per-lane ones the eager */
+template <bool WIDE, bool UNI>
+DBK_HD void luma_seg(Taps &a, Taps &b, int beta, int tc, int max_v, int ablate)
+{
+    if constexpr (UNI) luma_pairs<WIDE, true>(a, b, LumaKLazy<false>{beta, tc}, max_v, ablate);
+    else luma_pairs<WIDE, false>(a, b, LumaKEager::make<false>(beta, tc), max_v, ablate);
+}
+
+/* UNI: one QP for the whole launch (q.beta[] / q.tc[] hold four copies of two scalars), the segment constants are
+ * wave-uniform and live in SGPRs; otherwise (per-CTU QP map) they are per-lane values */
+template <bool WIDE = false, bool UNI = true>
 DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const BlockBs &bs, const BlockQp &q,
                             int max_v, Taps &ha, Taps &hb, Taps &ga, Taps &gb, int ablate = 0)
 {
-    if (bs.ver1 > 0) luma_pairs<WIDE>(va1, vb1, q.beta[0], q.tc[0], max_v, ablate); /* cpu.h:164 */
-    if (bs.ver2 > 0) luma_pairs<WIDE>(va2, vb2, q.beta[1], q.tc[1], max_v, ablate); /* cpu.h:228 */
+    if (bs.ver1 > 0) luma_seg<WIDE, UNI>(va1, vb1, q.beta[0], q.tc[0], max_v, ablate); /* cpu.h:164 */
+    if (bs.ver2 > 0) luma_seg<WIDE, UNI>(va2, vb2, q.beta[1], q.tc[1], max_v, ablate); /* cpu.h:228 */
     diag_barriers(ablate);
 
     /* hor1: lines = cols 0..3, pair A = cols (0,3) = ver taps (p3,p0), pair B = cols (1,2) = (p2,p1);
@@ -539,7 +621,7 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
     ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1); /* row 5 */
     ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1); /* row 6 */
     ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1); /* row 7 */
-    if (bs.hor1 > 0) luma_pairs<WIDE>(ha, hb, q.beta[2], q.tc[2], max_v, ablate); /* cpu.h:292 */
+    if (bs.hor1 > 0) luma_seg<WIDE, UNI>(ha, hb, q.beta[2], q.tc[2], max_v, ablate); /* cpu.h:292 */
     diag_barriers(ablate);
 
     /* hor2: P lines = cols 4..7 (ver taps q0..q3) of rows 3..0, pair A = cols (4,7), B = cols (5,6);
@@ -550,17 +632,18 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
     ga.p3 = pick_lo(va1.q0, va1.q3); gb.p3 = pick_lo(va1.q1, va1.q2); /* row 0 */
     ga.q0 = ha.q0; ga.q1 = ha.q1; ga.q2 = ha.q2; ga.q3 = ha.q3;
     gb.q0 = hb.q0; gb.q1 = hb.q1; gb.q2 = hb.q2; gb.q3 = hb.q3;
-    if (bs.hor2 > 0) luma_pairs<WIDE>(ga, gb, q.beta[3], q.tc[3], max_v, ablate); /* cpu.h:373 */
+    if (bs.hor2 > 0) luma_seg<WIDE, UNI>(ga, gb, q.beta[3], q.tc[3], max_v, ablate); /* cpu.h:373 */
     diag_barriers(ablate);
 }
 
 /* 8-bit samples: L[r] = cols 0..3, R[r] = cols 4..7 of row r as bytes */
+template <bool UNI = true>
 DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, const BlockQp &q, int ablate = 0)
 {
     Taps va1 = unpack_ver(L[0], L[3], R[0], R[3]), vb1 = unpack_ver(L[1], L[2], R[1], R[2]);
     Taps va2 = unpack_ver(L[4], L[7], R[4], R[7]), vb2 = unpack_ver(L[5], L[6], R[5], R[6]);
     Taps ha, hb, ga, gb;
-    luma_block_core(va1, vb1, va2, vb2, bs, q, 255, ha, hb, ga, gb, ablate);
+    luma_block_core<false, UNI>(va1, vb1, va2, vb2, bs, q, 255, ha, hb, ga, gb, ablate);
 
     /* final pack, once per row dword */
     L[0] = row_of(ha.p3, hb.p3); L[1] = row_of(ha.p2, hb.p2); L[2] = row_of(ha.p1, hb.p1); L[3] = row_of(ha.p0, hb.p0);
@@ -591,13 +674,13 @@ DBK_HD Taps unpack_ver16(const uint32_t (&a)[4], const uint32_t (&b)[4])
     return t;
 }
 
-template <bool WIDE = false>
+template <bool WIDE = false, bool UNI = true>
 DBK_HD void packed_filter_luma_block16(uint32_t (&W)[8][4], const BlockBs &bs, const BlockQp &q, int max_v)
 {
     Taps va1 = unpack_ver16(W[0], W[3]), vb1 = unpack_ver16(W[1], W[2]);
     Taps va2 = unpack_ver16(W[4], W[7]), vb2 = unpack_ver16(W[5], W[6]);
     Taps ha, hb, ga, gb;
-    luma_block_core<WIDE>(va1, vb1, va2, vb2, bs, q, max_v, ha, hb, ga, gb);
+    luma_block_core<WIDE, UNI>(va1, vb1, va2, vb2, bs, q, max_v, ha, hb, ga, gb);
 
     /* pair A = cols (0,3) / (4,7), pair B = cols (1,2) / (5,6):  (c0,c1) = (A.lo,B.lo), (c2,c3) = (B.hi,A.hi) */
 #define DBK_ROW16(r, A, B, j)                                 \
@@ -615,7 +698,7 @@ DBK_HD void packed_filter_luma_block16(uint32_t (&W)[8][4], const BlockBs &bs, c
 }
 
 /* ---- the whole block: ver1 -> ver2 -> hor1 -> hor2 --------------------------------------- */
-template <bool CHROMA>
+template <bool CHROMA, bool UNI = true>
 DBK_HD void packed_filter_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, const BlockQp &q, int ablate = 0)
 {
     if constexpr (CHROMA) {
@@ -624,7 +707,7 @@ DBK_HD void packed_filter_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockB
         if (bs.hor1 == 2) chroma_hor(L, L, q.tc[2]);
         if (bs.hor2 == 2) chroma_hor(R, L, q.tc[3]);
     } else {
-        packed_filter_luma_block(L, R, bs, q, ablate);
+        packed_filter_luma_block<UNI>(L, R, bs, q, ablate);
     }
 }
 

@@ -85,8 +85,42 @@ DBK_HD void normal_pair_h265(Taps &t, int tc, pk mp0, pk mq0, pk mp1, pk mq1)
     t.q1 = t.q1 + (dq1 & on & mq1);
 }
 
-/* one luma segment from its two pairs; entry = bS byte with the keep flags; beta / tc already looked up */
+/* the per-block scalars of the one-QP spec-exact kernels: beta is one scalar, tc one of two (bS 1 / bS 2) */
+struct H265Uni {
+    int beta, tc1, tc2;
+};
+DBK_HD H265Uni h265_uni(int beta, int tc_bs1, int tc_bs2)
+{
+    H265Uni u;
+    u.beta = beta; u.tc1 = tc_bs1; u.tc2 = tc_bs2;
+    return u;
+}
+
+/*
+ * One luma segment, one-QP kernels (round 3).  In nearly every wave the lanes that filter share ONE bS value and nobody
+ * carries a keep flag (PCM / transquant bypass are rare, and a picture's edges are mostly intra = 2 or mostly inter = 1):
+ * such a wave runs the SAME code as the reference-exact kernel -- decisions through saturating subtractions and biased
+ * adds, the three-instruction strong clamp, one conservative |delta| test, operands in SGPRs -- with the standard's
+ * thresholds and clip (LumaKLazy<true>).  A wave with mixed bS or a keep flag takes the general per-lane form below.
+ */
 template <bool WIDE = false>
+DBK_HD void luma_pairs_h265(Taps &a, Taps &b, int entry, int beta, int tc, int max_v);
+template <bool WIDE = false>
+DBK_HD void luma_pairs_h265_uni(Taps &a, Taps &b, int entry, int beta, int tc, int max_v, const H265Uni &u)
+{
+    const int bs = entry & kH265BsMask;
+    const unsigned long long m1 = lane_ballot(bs == 1), m2 = lane_ballot(bs == 2);
+    const unsigned long long mk = lane_ballot(bs != 0 && (entry & (kH265KeepP | kH265KeepQ)) != 0);
+    if (mk == 0ull && (m1 == 0ull || m2 == 0ull)) {
+        /* the wave's one tc is picked on the scalar unit and the segment constants are built from it right here */
+        if (bs != 0) luma_pairs<WIDE, true>(a, b, LumaKLazy<true>{u.beta, m2 != 0ull ? u.tc2 : u.tc1}, max_v);
+    } else {
+        luma_pairs_h265<WIDE>(a, b, entry, beta, tc, max_v);
+    }
+}
+
+/* one luma segment from its two pairs; entry = bS byte with the keep flags; beta / tc already looked up */
+template <bool WIDE>
 DBK_HD void luma_pairs_h265(Taps &a, Taps &b, int entry, int beta, int tc, int max_v)
 {
     if ((entry & kH265BsMask) == 0) return;
@@ -120,14 +154,21 @@ struct H265Seg {
     int entry[4]; /* bS bytes: ver1, ver2, hor1, hor2 */
     int tc[4], beta[4];
 };
+/* a segment of a one-QP kernel (u != NULL) or of a QP-map kernel */
+template <bool WIDE = false>
+DBK_HD void luma_seg_h265(Taps &a, Taps &b, const H265Seg &s, int i, int max_v, const H265Uni *u)
+{
+    if (u) luma_pairs_h265_uni<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v, *u);
+    else luma_pairs_h265<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v);
+}
 
 /* 8-bit luma block: ver1 -> ver2 -> hor1 -> hor2 with the conformant hor2 (P and Q both in columns 4..7) */
-DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], const H265Seg &s)
+DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], const H265Seg &s, const H265Uni *u = nullptr)
 {
     Taps va1 = unpack_ver(L[0], L[3], R[0], R[3]), vb1 = unpack_ver(L[1], L[2], R[1], R[2]);
     Taps va2 = unpack_ver(L[4], L[7], R[4], R[7]), vb2 = unpack_ver(L[5], L[6], R[5], R[6]);
-    luma_pairs_h265(va1, vb1, s.entry[0], s.beta[0], s.tc[0], 255);
-    luma_pairs_h265(va2, vb2, s.entry[1], s.beta[1], s.tc[1], 255);
+    luma_seg_h265(va1, vb1, s, 0, 255, u);
+    luma_seg_h265(va2, vb2, s, 1, 255, u);
 
     Taps ha, hb, ga, gb;
     /* hor1: lines = cols 0..3 (ver taps p3..p0), P_k = row 3-k, Q_k = row 4+k */
@@ -139,7 +180,7 @@ DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], co
     ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1);
     ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1);
     ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1);
-    luma_pairs_h265(ha, hb, s.entry[2], s.beta[2], s.tc[2], 255);
+    luma_seg_h265(ha, hb, s, 2, 255, u);
     /* hor2: lines = cols 4..7 (ver taps q0..q3), same rows */
     ga.p0 = pick_hi(va1.q0, va1.q3); gb.p0 = pick_hi(va1.q1, va1.q2);
     ga.p1 = pick_hi(vb1.q0, vb1.q3); gb.p1 = pick_hi(vb1.q1, vb1.q2);
@@ -149,7 +190,7 @@ DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], co
     ga.q1 = pick_lo(vb2.q0, vb2.q3); gb.q1 = pick_lo(vb2.q1, vb2.q2);
     ga.q2 = pick_hi(vb2.q0, vb2.q3); gb.q2 = pick_hi(vb2.q1, vb2.q2);
     ga.q3 = pick_hi(va2.q0, va2.q3); gb.q3 = pick_hi(va2.q1, va2.q2);
-    luma_pairs_h265(ga, gb, s.entry[3], s.beta[3], s.tc[3], 255);
+    luma_seg_h265(ga, gb, s, 3, 255, u);
 
     L[0] = row_of(ha.p3, hb.p3); L[1] = row_of(ha.p2, hb.p2); L[2] = row_of(ha.p1, hb.p1); L[3] = row_of(ha.p0, hb.p0);
     L[4] = row_of(ha.q0, hb.q0); L[5] = row_of(ha.q1, hb.q1); L[6] = row_of(ha.q2, hb.q2); L[7] = row_of(ha.q3, hb.q3);
@@ -200,7 +241,7 @@ DBK_HD void chroma_hor_h265(uint32_t (&X)[8], int tc, int entry)
 }
 
 template <bool CHROMA>
-DBK_HD void packed_filter_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], const H265Seg &s)
+DBK_HD void packed_filter_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], const H265Seg &s, const H265Uni *u = nullptr)
 {
     if constexpr (CHROMA) {
         chroma_ver_h265<0>(L, R, s.tc[0], s.entry[0]);
@@ -208,7 +249,7 @@ DBK_HD void packed_filter_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], const H
         chroma_hor_h265(L, s.tc[2], s.entry[2]);
         chroma_hor_h265(R, s.tc[3], s.entry[3]);
     } else {
-        packed_filter_luma_block_h265(L, R, s);
+        packed_filter_luma_block_h265(L, R, s, u);
     }
 }
 

@@ -70,8 +70,14 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
                 uint32_t W[8][4];
                 for (int r = 0; r < 8; r++)
                     for (int j = 0; j < 4; j++) W[r][j] = (uint32_t)v[r][2 * j] | ((uint32_t)v[r][2 * j + 1] << 16);
-                if (max_v > 2047) dbk::packed_filter_luma_block16<true>(W, bs, q, max_v); /* 12 bit: wide sums */
-                else dbk::packed_filter_luma_block16(W, bs, q, max_v);
+                /* UNI (second template argument) exactly as the kernels instantiate it: one QP => true, QP map => false */
+                if (max_v > 2047) { /* 12 bit: wide sums */
+                    if (map) dbk::packed_filter_luma_block16<true, false>(W, bs, q, max_v);
+                    else dbk::packed_filter_luma_block16<true, true>(W, bs, q, max_v);
+                } else {
+                    if (map) dbk::packed_filter_luma_block16<false, false>(W, bs, q, max_v);
+                    else dbk::packed_filter_luma_block16<false, true>(W, bs, q, max_v);
+                }
                 for (int r = 0; r < 8; r++)
                     for (int j = 0; j < 4; j++) {
                         v[r][2 * j] = W[r][j] & 0xffff;
@@ -100,7 +106,8 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
                     R[r] = (uint32_t)v[r][4] | ((uint32_t)v[r][5] << 8) | ((uint32_t)v[r][6] << 16) | ((uint32_t)v[r][7] << 24);
                 }
                 if (is_chroma) dbk::packed_filter_block<true>(L, R, bs, q);
-                else dbk::packed_filter_block<false>(L, R, bs, q);
+                else if (map) dbk::packed_filter_block<false, false>(L, R, bs, q);
+                else dbk::packed_filter_block<false, true>(L, R, bs, q);
                 for (int r = 0; r < 8; r++)
                     for (int c = 0; c < 4; c++) {
                         v[r][c] = (L[r] >> (8 * c)) & 0xff;
@@ -148,6 +155,14 @@ static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint
                      const uint8_t *map, int map_stride, int unit_log2, const dbk::H265Prm &prm, int packed)
 {
     const int nbx = w / 8 + 1, nby = h / 8 + 1, sc = c_idx ? 2 : 1;
+#if HAVE_PACKED
+    /* the one-QP kernels' per-block scalars, derived as dbk_launch_packed_h265 derives them (luma); a block is a "wave" of
+     * one lane here, so every block without keep flags takes the uniform path and every block with one the general path */
+    const dbk::H265Uni uni = dbk::h265_uni(dbk::h265_beta(dbk::clampi(qp + prm.beta_off, 0, 51)) << prm.shift,
+                                           dbk::h265_tc(dbk::clampi(qp + prm.tc_off, 0, 53)) << prm.shift,
+                                           dbk::h265_tc(dbk::clampi(qp + 2 + prm.tc_off, 0, 53)) << prm.shift);
+    const dbk::H265Uni *const u = (map || c_idx) ? nullptr : &uni;
+#endif
     for (int by = 0; by < nby; by++)
         for (int bx = 0; bx < nbx; bx++) {
             int v[8][8], entry[4], qpl[4];
@@ -163,8 +178,8 @@ static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint
                 if (c_idx) { dbk::h265_seg_params<true>(entry, qpl, prm, sg); dbk::packed_filter_block16_h265<true>(W, sg, prm.max_v); }
                 else {
                     dbk::h265_seg_params<false>(entry, qpl, prm, sg);
-                    if (prm.max_v > 2047) dbk::packed_filter_block16_h265<false, true>(W, sg, prm.max_v);
-                    else dbk::packed_filter_block16_h265<false>(W, sg, prm.max_v);
+                    if (prm.max_v > 2047) dbk::packed_filter_block16_h265<false, true>(W, sg, prm.max_v, u);
+                    else dbk::packed_filter_block16_h265<false>(W, sg, prm.max_v, u);
                 }
                 for (int r = 0; r < 8; r++)
                     for (int j = 0; j < 4; j++) {
@@ -182,7 +197,7 @@ static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint
                 }
                 dbk::H265Seg sg;
                 if (c_idx) { dbk::h265_seg_params<true>(entry, qpl, prm, sg); dbk::packed_filter_block_h265<true>(L, R, sg); }
-                else { dbk::h265_seg_params<false>(entry, qpl, prm, sg); dbk::packed_filter_block_h265<false>(L, R, sg); }
+                else { dbk::h265_seg_params<false>(entry, qpl, prm, sg); dbk::packed_filter_block_h265<false>(L, R, sg, u); }
                 for (int r = 0; r < 8; r++)
                     for (int c = 0; c < 4; c++) {
                         v[r][c] = (L[r] >> (8 * c)) & 0xff;

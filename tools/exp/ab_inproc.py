@@ -8,8 +8,8 @@ the builds take turns -- A B C A B C ... -- each turn one uninterrupted settle +
 library without that entry, i.e. round 2's, gets settle launches + hevcdbk_device_run_timed).  Per build: mean / median of
 the per-turn means, and the ratio to the first build turn by turn.
 
-    python3 tools/exp/ab_inproc.py [--rounds 6] [--steps 120] [--frames 256] name=path[:variant] ...
-variant: auto (default) | copy (diagnostic library only)
+    python3 tools/exp/ab_inproc.py [--rounds 6] [--steps 120] [--frames 256] name=path[:variant[:diag knobs]] ...
+variant: auto (default) | copy (diagnostic library only); diag knobs: hevcdbk_diag_set() string of the diagnostic library, e.g. wg=256
 """
 import argparse
 import ctypes as C
@@ -27,7 +27,7 @@ from gpu_video_codec_amd import synth  # noqa: E402
 
 
 class Lib:
-    def __init__(self, name, path, variant):
+    def __init__(self, name, path, variant, diag=None):
         self.name, self.path = name, path
         self.variant = {"auto": 0, "packed": 2, "copy": 100}[variant]
         self.L = C.CDLL(os.path.abspath(path), mode=os.RTLD_LOCAL | os.RTLD_NOW)
@@ -45,7 +45,8 @@ class Lib:
                                                      C.POINTER(L0.Replay), C.POINTER(C.c_float)]
         if self.variant == 100 or "diag" in os.path.basename(path):
             self.L.hevcdbk_diag_set.argtypes = [C.c_char_p]
-            self.L.hevcdbk_diag_set(None)
+            if self.L.hevcdbk_diag_set(diag.encode() if diag else None) != 0:
+                raise SystemExit("%s: hevcdbk_diag_set(%r) refused" % (name, diag))
         h = C.c_void_p()
         rc = self.L.hevcdbk_create(0, C.byref(h))
         if rc:
@@ -89,8 +90,8 @@ def main():
     libs = []
     for spec in a.libs:
         name, rest = spec.split("=", 1)
-        path, _, variant = rest.partition(":")
-        libs.append(Lib(name, path, variant or "auto"))
+        parts = rest.split(":")
+        libs.append(Lib(name, parts[0], (parts[1] if len(parts) > 1 and parts[1] else "auto"), parts[2] if len(parts) > 2 else None))
     A = libs[0]
     base = [synth.blocky_plane(w, h, seed=1, frame=i) for i in range(4)]
     frames = np.empty((F, h, w), np.uint8)

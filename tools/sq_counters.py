@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--variant", default="packed")
     ap.add_argument("--tag", default=None)
     ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--lib", default=None, help="another build of libhevcdbk.so (tools/bench_with_lib.py): same-box comparison of two kernel versions")
     args, extra = ap.parse_known_args()
     tag = args.tag or args.variant
     outdir = os.path.join(ROOT, "gpurun_out", "sq")
@@ -27,8 +28,8 @@ def main():
     res = {}
     for i, ctrs in enumerate(PASSES):
         d = os.path.join(outdir, "%s_pass%d" % (tag, i))
-        cmd = ["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--settle-max-ms", "20", "--copy-floor", "off", "--no-telemetry", "--variant", args.variant,
+        prog = [os.path.join(ROOT, "bench.py")] if args.lib is None else [os.path.join(ROOT, "tools", "bench_with_lib.py"), os.path.abspath(args.lib)]
+        cmd = ["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--", sys.executable] + prog + ["--steps", "5", "--warmup", "1", "--settle-max-ms", "20", "--copy-floor", "off", "--no-telemetry", "--variant", args.variant,
                "--frames", str(args.frames), "--no-cpu-baseline", "--no-e2e", "--no-extra", "--traffic", "none"] + extra
         r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, cwd=ROOT)
         if r.returncode:
