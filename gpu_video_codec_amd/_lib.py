@@ -38,6 +38,7 @@ EXPORTS = [
     "hevcdbk_h265_num_vert_bs", "hevcdbk_h265_num_hor_bs", "hevcdbk_h265_derive_bs_device",
     "hevc_deblocking_filter_h265_device", "hevc_deblocking_filter_h265", "hevc_sao_filter_device",
     "hevc_deblock_sao_device", "hevc_deblock_sao_h265_device",
+    "hevc_deblock_sao_device_planes", "hevc_deblock_sao_h265_device_planes",
 ]
 
 
@@ -58,6 +59,12 @@ class Qp(C.Structure):
 
 class Tables(C.Structure):
     _fields_ = [("tc", C.c_void_p), ("beta", C.c_void_p)]
+
+
+class SaoPlane(C.Structure):
+    """hevcdbk_sao_plane: the SAO operands of one plane of a multi-plane deblocking + SAO call (device pointers)"""
+    _fields_ = [("params", C.c_void_p), ("params_stride", C.c_uint), ("params_frame_stride", C.c_size_t), ("ctb_log2", C.c_uint),
+                ("keep", C.c_void_p), ("keep_stride", C.c_uint), ("keep_frame_stride", C.c_size_t)]
 
 
 class Replay(C.Structure):
@@ -196,6 +203,10 @@ def lib():
         L.hevc_deblock_sao_h265_device.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_int, C.c_uint, C.POINTER(H265Params),
                                                    C.c_void_p, C.c_uint, C.c_size_t, C.c_uint, C.c_void_p, C.c_uint, C.c_size_t,
                                                    C.c_int, C.c_void_p]
+        L.hevc_deblock_sao_device_planes.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint, C.c_uint, C.POINTER(Tables),
+                                                     C.POINTER(SaoPlane), C.c_int, C.c_void_p]
+        L.hevc_deblock_sao_h265_device_planes.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint, C.c_uint, C.POINTER(H265Params),
+                                                          C.POINTER(SaoPlane), C.c_int, C.c_void_p]
         _lib = L
     return _lib
 

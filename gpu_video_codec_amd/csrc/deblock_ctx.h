@@ -27,6 +27,8 @@ struct hevcdbk_context {
     Growable pin[3], dev[3];
     Growable pin_bs, dev_bs, dev_map, dev_units;
     Growable dev_tmp; /* the deblocked planes between the two launches of hevc_deblock_sao_*_device where the fused kernel does not apply */
+    hipEvent_t tmp_ev = nullptr; /* end of the last launch that read dev_tmp: the next user of the scratch plane waits for it */
+    bool tmp_used = false;
     std::vector<hipEvent_t> timed_events;
     /* streaming operator: ring of kSeqSlots frames in flight */
     static constexpr int kSeqSlots = 3;

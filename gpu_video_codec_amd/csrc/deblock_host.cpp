@@ -399,6 +399,7 @@ void hevcdbk_destroy(hevcdbk_context *ctx)
     if (ctx->dev_map.p) (void)hipFree(ctx->dev_map.p);
     if (ctx->dev_units.p) (void)hipFree(ctx->dev_units.p);
     if (ctx->dev_tmp.p) (void)hipFree(ctx->dev_tmp.p);
+    if (ctx->tmp_ev) (void)hipEventDestroy(ctx->tmp_ev);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->timed_events) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < hevcdbk_context::kSeqSlots; k++)

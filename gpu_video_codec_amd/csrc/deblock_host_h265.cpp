@@ -240,16 +240,64 @@ int sao_args(const hevcdbk_device_planes *p, const hevcdbk_sao_ctb *params, unsi
     return HEVCDBK_OK;
 }
 
-/* the two-launch form of deblocking + SAO: the deblocked planes go through ctx->dev_tmp (same pitch and frame stride) */
-int tmp_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *p, hevcdbk_device_planes &first, hevcdbk_device_planes &second)
+/* the two-launch form of deblocking + SAO: the deblocked planes go through ctx->dev_tmp (same pitch and frame stride).
+ * The scratch plane is ONE buffer per context while the caller may hand in any stream: the previous user's SAO launch is
+ * fenced by an event (ctx->tmp_ev) that the next user's stream waits for before it overwrites the scratch, and the buffer
+ * is only re-allocated after that event has completed (two calls on different streams raced on it) */
+int tmp_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *p, hipStream_t s, hevcdbk_device_planes &first,
+               hevcdbk_device_planes &second)
 {
     const size_t bytes = (size_t)p->frame_stride * (p->n_frames ? p->n_frames - 1 : 0) + (size_t)p->pitch * p->plane_h;
+    if (!ctx->tmp_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->tmp_ev, hipEventDisableTiming));
+    if (ctx->tmp_used) {
+        if (ctx->dev_tmp.cap < bytes) HIP_TRY(ctx, hipEventSynchronize(ctx->tmp_ev)); /* about to free it */
+        else HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->tmp_ev, 0));
+    }
     if (int rc = grow_device(ctx, ctx->dev_tmp, bytes)) return rc;
     first = *p;
     first.dst = ctx->dev_tmp.p;
     second = *p;
     second.src = ctx->dev_tmp.p;
     return HEVCDBK_OK;
+}
+int tmp_done(hevcdbk_context *ctx, hipStream_t s)
+{
+    HIP_TRY(ctx, hipEventRecord(ctx->tmp_ev, s));
+    ctx->tmp_used = true;
+    return HEVCDBK_OK;
+}
+
+/* one plane: the fused kernel where it applies (and is not switched off), else the two launches */
+int deblock_sao_plane(hevcdbk_context *ctx, const hevcdbk_device_planes *p, unsigned qp, const hevcdbk_tables *tables, DbkArgs &da,
+                      DbkSaoArgs &sa, int fused, hipStream_t s)
+{
+    const bool can = dbk_deblock_sao_supports(da, sa, (int)p->sample_bytes, p->is_chroma != 0);
+    if (fused == HEVCDBK_FUSED_ON && !can) return HEVCDBK_ERR_UNSUPPORTED;
+    if (can && fused != HEVCDBK_FUSED_OFF)
+        return hip_ok(ctx, dbk_launch_deblock_sao(da, sa, (int)p->sample_bytes, p->is_chroma != 0, s), "fused deblocking + SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    hevcdbk_device_planes first, second;
+    if (int rc = tmp_planes(ctx, p, s, first, second)) return rc;
+    if (int rc = planes_to_args(&first, qp, tables, da)) return rc;
+    if (int rc = launch(ctx, da, (int)p->sample_bytes, p->is_chroma != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
+    sa.src = (const uint8_t *)second.src;
+    if (!hip_ok(ctx, dbk_launch_sao(sa, (int)p->sample_bytes, s), "SAO launch")) return HEVCDBK_ERR_HIP;
+    return tmp_done(ctx, s);
+}
+int deblock_sao_plane_h265(hevcdbk_context *ctx, const hevcdbk_device_planes *p, int c_idx, unsigned qp, const hevcdbk_h265_params *prm,
+                           DbkH265Args &h, DbkSaoArgs &sa, int fused, hipStream_t s)
+{
+    const bool can = dbk_packed_h265_supports(h, (int)p->sample_bytes, c_idx != 0) &&
+                     dbk_deblock_sao_supports(h.base, sa, (int)p->sample_bytes, c_idx != 0);
+    if (fused == HEVCDBK_FUSED_ON && !can) return HEVCDBK_ERR_UNSUPPORTED;
+    if (can && fused != HEVCDBK_FUSED_OFF)
+        return hip_ok(ctx, dbk_launch_deblock_sao_h265(h, sa, (int)p->sample_bytes, c_idx != 0, s), "fused deblocking + SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    hevcdbk_device_planes first, second;
+    if (int rc = tmp_planes(ctx, p, s, first, second)) return rc;
+    if (int rc = h265_args(&first, c_idx, qp, prm, h)) return rc;
+    if (int rc = launch_h265(ctx, h, (int)p->sample_bytes, c_idx != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
+    sa.src = (const uint8_t *)second.src;
+    if (!hip_ok(ctx, dbk_launch_sao(sa, (int)p->sample_bytes, s), "SAO launch")) return HEVCDBK_ERR_HIP;
+    return tmp_done(ctx, s);
 }
 
 } /* namespace */
@@ -278,17 +326,7 @@ int hevc_deblock_sao_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p
     DbkArgs da;
     if (int rc = planes_to_args(p, qp, tables, da)) return rc;
     if (int rc = bind(ctx)) return rc;
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
-    const bool can = dbk_deblock_sao_supports(da, sa, (int)p->sample_bytes, p->is_chroma != 0);
-    if (fused == HEVCDBK_FUSED_ON && !can) return HEVCDBK_ERR_UNSUPPORTED;
-    if (can && fused != HEVCDBK_FUSED_OFF)
-        return hip_ok(ctx, dbk_launch_deblock_sao(da, sa, p->is_chroma != 0, s), "fused deblocking + SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
-    hevcdbk_device_planes first, second;
-    if (int rc = tmp_planes(ctx, p, first, second)) return rc;
-    if (int rc = planes_to_args(&first, qp, tables, da)) return rc;
-    if (int rc = launch(ctx, da, (int)p->sample_bytes, p->is_chroma != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
-    sa.src = (const uint8_t *)second.src;
-    return hip_ok(ctx, dbk_launch_sao(sa, (int)p->sample_bytes, s), "SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    return deblock_sao_plane(ctx, p, qp, tables, da, sa, fused, hip_stream ? (hipStream_t)hip_stream : ctx->compute);
 }
 
 int hevc_deblock_sao_h265_device(hevcdbk_context *ctx, const hevcdbk_device_planes *p, int c_idx, unsigned qp,
@@ -302,18 +340,76 @@ int hevc_deblock_sao_h265_device(hevcdbk_context *ctx, const hevcdbk_device_plan
     DbkH265Args h;
     if (int rc = h265_args(p, c_idx, qp, prm, h)) return rc;
     if (int rc = bind(ctx)) return rc;
+    return deblock_sao_plane_h265(ctx, p, c_idx, qp, prm, h, sa, fused, hip_stream ? (hipStream_t)hip_stream : ctx->compute);
+}
+
+/* ---- Y, U, V of a batch: deblocking + SAO of all planes in ONE launch where the fused kernel takes every plane ---- */
+
+int hevc_deblock_sao_device_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes, unsigned qp,
+                                   const hevcdbk_tables *tables, const hevcdbk_sao_plane *sao, int fused, void *hip_stream)
+{
+    if (!ctx || !planes || !sao || n_planes == 0 || n_planes > 3 ||
+        (fused != HEVCDBK_FUSED_AUTO && fused != HEVCDBK_FUSED_OFF && fused != HEVCDBK_FUSED_ON))
+        return HEVCDBK_ERR_ARG;
+    DbkArgs da[3];
+    DbkSaoArgs sa[3];
+    bool one = n_planes >= 2 && fused != HEVCDBK_FUSED_OFF && !planes[0].is_chroma;
+    for (unsigned i = 0; i < n_planes; i++) {
+        if (int rc = sao_args(&planes[i], sao[i].params, sao[i].params_stride, sao[i].params_frame_stride, sao[i].ctb_log2, sao[i].keep,
+                              sao[i].keep_stride, sao[i].keep_frame_stride, sa[i]))
+            return rc;
+        if (int rc = planes_to_args(&planes[i], qp, tables, da[i])) return rc;
+        if (planes[i].n_frames != planes[0].n_frames) return HEVCDBK_ERR_ARG;
+        one = one && (i == 0 || planes[i].is_chroma) && planes[i].sample_bytes == planes[0].sample_bytes &&
+              planes[i].bit_depth == planes[0].bit_depth &&
+              dbk_deblock_sao_supports(da[i], sa[i], (int)planes[i].sample_bytes, planes[i].is_chroma != 0);
+    }
+    if (int rc = bind(ctx)) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
-    const bool can = dbk_packed_h265_supports(h, (int)p->sample_bytes, c_idx != 0) &&
-                     dbk_deblock_sao_supports(h.base, sa, (int)p->sample_bytes, c_idx != 0);
-    if (fused == HEVCDBK_FUSED_ON && !can) return HEVCDBK_ERR_UNSUPPORTED;
-    if (can && fused != HEVCDBK_FUSED_OFF)
-        return hip_ok(ctx, dbk_launch_deblock_sao_h265(h, sa, c_idx != 0, s), "fused deblocking + SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
-    hevcdbk_device_planes first, second;
-    if (int rc = tmp_planes(ctx, p, first, second)) return rc;
-    if (int rc = h265_args(&first, c_idx, qp, prm, h)) return rc;
-    if (int rc = launch_h265(ctx, h, (int)p->sample_bytes, c_idx != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
-    sa.src = (const uint8_t *)second.src;
-    return hip_ok(ctx, dbk_launch_sao(sa, (int)p->sample_bytes, s), "SAO launch") ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    if (one)
+        return hip_ok(ctx, dbk_launch_deblock_sao_multi(da, sa, (int)n_planes, (int)planes[0].sample_bytes, s), "fused deblocking + SAO launch")
+                   ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    /* plane by plane; every plane is checked before the first launch */
+    if (fused == HEVCDBK_FUSED_ON)
+        for (unsigned i = 0; i < n_planes; i++)
+            if (!dbk_deblock_sao_supports(da[i], sa[i], (int)planes[i].sample_bytes, planes[i].is_chroma != 0)) return HEVCDBK_ERR_UNSUPPORTED;
+    for (unsigned i = 0; i < n_planes; i++)
+        if (int rc = deblock_sao_plane(ctx, &planes[i], qp, tables, da[i], sa[i], fused, s)) return rc;
+    return HEVCDBK_OK;
+}
+
+int hevc_deblock_sao_h265_device_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes, unsigned qp,
+                                        const hevcdbk_h265_params *prm, const hevcdbk_sao_plane *sao, int fused, void *hip_stream)
+{
+    if (!ctx || !planes || !sao || n_planes == 0 || n_planes > 3 ||
+        (fused != HEVCDBK_FUSED_AUTO && fused != HEVCDBK_FUSED_OFF && fused != HEVCDBK_FUSED_ON))
+        return HEVCDBK_ERR_ARG;
+    DbkH265Args h[3];
+    DbkSaoArgs sa[3];
+    bool can[3] = {false, false, false};
+    bool one = n_planes >= 2 && fused != HEVCDBK_FUSED_OFF && !planes[0].is_chroma;
+    for (unsigned i = 0; i < n_planes; i++) {
+        if (int rc = sao_args(&planes[i], sao[i].params, sao[i].params_stride, sao[i].params_frame_stride, sao[i].ctb_log2, sao[i].keep,
+                              sao[i].keep_stride, sao[i].keep_frame_stride, sa[i]))
+            return rc;
+        if (int rc = h265_args(&planes[i], (int)i, qp, prm, h[i])) return rc; /* c_idx = plane index: 0 Y, 1 Cb, 2 Cr */
+        if (planes[i].n_frames != planes[0].n_frames) return HEVCDBK_ERR_ARG;
+        can[i] = dbk_packed_h265_supports(h[i], (int)planes[i].sample_bytes, i != 0) &&
+                 dbk_deblock_sao_supports(h[i].base, sa[i], (int)planes[i].sample_bytes, i != 0);
+        one = one && (i == 0 || planes[i].is_chroma) && planes[i].sample_bytes == planes[0].sample_bytes &&
+              planes[i].bit_depth == planes[0].bit_depth && can[i];
+    }
+    if (int rc = bind(ctx)) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;
+    if (one)
+        return hip_ok(ctx, dbk_launch_deblock_sao_multi_h265(h, sa, (int)n_planes, (int)planes[0].sample_bytes, s), "fused deblocking + SAO launch")
+                   ? HEVCDBK_OK : HEVCDBK_ERR_HIP;
+    if (fused == HEVCDBK_FUSED_ON)
+        for (unsigned i = 0; i < n_planes; i++)
+            if (!can[i]) return HEVCDBK_ERR_UNSUPPORTED;
+    for (unsigned i = 0; i < n_planes; i++)
+        if (int rc = deblock_sao_plane_h265(ctx, &planes[i], (int)i, qp, prm, h[i], sa[i], fused, s)) return rc;
+    return HEVCDBK_OK;
 }
 
 } /* extern "C" */

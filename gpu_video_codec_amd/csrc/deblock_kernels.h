@@ -164,7 +164,21 @@ struct DbkFusedH265Args {
     DbkSaoArgs s;
     DbkFusedGrid g;
 };
+/* the planes of a 4:2:0 batch in one fused launch: the grid is the planes' grids one after the other */
+struct DbkFusedMultiArgs {
+    DbkFusedArgs pl[3];
+    uint32_t wg_end[3]; /* cumulative grid sizes: blockIdx.x < wg_end[i] belongs to plane <= i */
+};
+struct DbkFusedMultiH265Args {
+    DbkFusedH265Args pl[3];
+    uint32_t wg_end[3];
+};
+/* 8-bit planes and 16-bit containers up to 12 bit, scalar QP */
 bool dbk_deblock_sao_supports(const DbkArgs &d, const DbkSaoArgs &s, int sample_bytes, bool chroma);
-hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, bool chroma, hipStream_t stream);
-hipError_t dbk_launch_deblock_sao_h265(const DbkH265Args &h, const DbkSaoArgs &s, bool chroma, hipStream_t stream);
+hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, int sample_bytes, bool chroma, hipStream_t stream);
+hipError_t dbk_launch_deblock_sao_h265(const DbkH265Args &h, const DbkSaoArgs &s, int sample_bytes, bool chroma, hipStream_t stream);
+/* n = 2 or 3 planes (plane 0 luma, the others chroma), every one accepted by dbk_deblock_sao_supports, one sample width
+ * and bit depth, one frame count */
+hipError_t dbk_launch_deblock_sao_multi(const DbkArgs *d, const DbkSaoArgs *s, int n, int sample_bytes, hipStream_t stream);
+hipError_t dbk_launch_deblock_sao_multi_h265(const DbkH265Args *h, const DbkSaoArgs *s, int n, int sample_bytes, hipStream_t stream);
 

@@ -1257,21 +1257,30 @@ hipError_t dbk_launch_packed_h265(const DbkH265Args &h, int sample_bytes, bool c
 /* ---- deblocking + SAO in one kernel ---- */
 bool dbk_deblock_sao_supports(const DbkArgs &d, const DbkSaoArgs &s, int sample_bytes, bool chroma)
 {
-    if (sample_bytes != 1 || d.max_v != 255 || s.max_v != 255 || s.band_shift != 3 || d.qp_map || d.by_count != 0) return false;
+    if (d.qp_map || d.by_count != 0 || d.max_v != s.max_v) return false;
+    if (sample_bytes == 1) {
+        if (d.max_v != 255 || s.band_shift != 3) return false;
+    } else {
+        /* 16-bit containers up to 12 bit; the SAO stage's output rows are 16-byte stores */
+        if (sample_bytes != 2 || d.max_v > 4095 || s.band_shift < 3 || (1 << (s.band_shift + 5)) - 1 != s.max_v) return false;
+    }
     if (!dbk_packed_supports(d, sample_bytes, chroma)) return false;
     if (d.plane_w != s.plane_w || d.plane_h != s.plane_h || d.n_frames != s.n_frames || d.n_frames > 65535) return false;
-    if ((unsigned long long)s.pitch * (unsigned long long)s.plane_h >= (1ull << 31) || s.pitch % 4 != 0 || s.frame_stride % 4 != 0 ||
-        ((uintptr_t)s.dst % 4) != 0)
+    const long long al = 4 * sample_bytes;
+    if ((unsigned long long)s.pitch * (unsigned long long)s.plane_h >= (1ull << 31) || s.pitch % al != 0 || s.frame_stride % al != 0 ||
+        ((uintptr_t)s.dst % al) != 0)
         return false;
-    const unsigned long long tiles = (unsigned long long)((d.plane_w + kFusedTileW - 1) / kFusedTileW) * ((d.plane_h + kFusedTile - 1) / kFusedTile);
+    const int tw = sample_bytes == 1 ? kFusedTileW : kFused16Tile, th = sample_bytes == 1 ? kFusedTile : kFused16Tile;
+    const unsigned long long tiles = (unsigned long long)((d.plane_w + tw - 1) / tw) * ((d.plane_h + th - 1) / th);
     return tiles * (unsigned long long)d.n_frames + 8 < (1ull << 31) && tiles * tiles < (1ull << 32) &&
            (tiles * d.n_frames + 8) * tiles < (1ull << 32); /* exact reciprocal divisions: dividend < 2^32 / divisor */
 }
 
 /* 1-D grid of the fused kernel, a multiple of 8 workgroups */
-static unsigned fused_grid(int plane_w, int plane_h, int n_frames, DbkFusedGrid &g)
+static unsigned fused_grid(int plane_w, int plane_h, int n_frames, int sample_bytes, DbkFusedGrid &g)
 {
-    const unsigned long long tx = (plane_w + kFusedTileW - 1) / kFusedTileW, ty = (plane_h + kFusedTile - 1) / kFusedTile, tpf = tx * ty;
+    const int tw = sample_bytes == 1 ? kFusedTileW : kFused16Tile, th = sample_bytes == 1 ? kFusedTile : kFused16Tile;
+    const unsigned long long tx = (plane_w + tw - 1) / tw, ty = (plane_h + th - 1) / th, tpf = tx * ty;
     g.tiles_x = (uint32_t)tx;
     g.tiles_per_frame = (uint32_t)tpf;
     g.total = (uint32_t)(tpf * n_frames);
@@ -1282,39 +1291,99 @@ static unsigned fused_grid(int plane_w, int plane_h, int n_frames, DbkFusedGrid 
     return grid;
 }
 
-hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, bool chroma, hipStream_t stream)
+/* the scalar-QP operands of the packed spec-exact kernels, as dbk_launch_packed_h265 derives them */
+static void fused_h265_scalars(DbkH265Args &d, bool chroma)
+{
+    auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const int sh = d.base.shift, qp = d.qp;
+    d.beta_s = dbk::h265_beta(cl(qp + d.beta_off, 0, 51)) << sh;
+    if (chroma) {
+        d.tc_bs1 = 0;
+        d.tc_bs2 = dbk::h265_tc(cl(dbk::h265_chroma_qp(qp + d.c_qp_offset) + 2 + d.tc_off, 0, 53)) << sh;
+    } else {
+        d.tc_bs1 = dbk::h265_tc(cl(qp + d.tc_off, 0, 53)) << sh;
+        d.tc_bs2 = dbk::h265_tc(cl(qp + 2 + d.tc_off, 0, 53)) << sh;
+    }
+}
+
+hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, int sample_bytes, bool chroma, hipStream_t stream)
 {
     if (d.n_frames <= 0 || d.nbx <= 0 || d.nby <= 0) return hipSuccess;
     DbkFusedArgs fa;
     fa.d = d;
     fa.s = s;
-    const dim3 grid(fused_grid(d.plane_w, d.plane_h, d.n_frames, fa.g), 1, 1), block(kFusedThreads, 1, 1);
-    if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused_kernel<true>), grid, block, kFusedLds, stream, fa);
-    else DBK_LAUNCH_LDS((dbk_sao_fused_kernel<false>), grid, block, kFusedLds, stream, fa);
+    const dim3 grid(fused_grid(d.plane_w, d.plane_h, d.n_frames, sample_bytes, fa.g), 1, 1);
+    if (sample_bytes == 1) {
+        if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused_kernel<true>), grid, dim3(kFusedThreads), kFusedLds, stream, fa);
+        else DBK_LAUNCH_LDS((dbk_sao_fused_kernel<false>), grid, dim3(kFusedThreads), kFusedLds, stream, fa);
+    } else {
+        if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused16_kernel<true, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
+        else if (d.max_v > 2047) DBK_LAUNCH_LDS((dbk_sao_fused16_kernel<false, true>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
+        else DBK_LAUNCH_LDS((dbk_sao_fused16_kernel<false, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
+    }
     return hipGetLastError();
 }
 
-hipError_t dbk_launch_deblock_sao_h265(const DbkH265Args &h, const DbkSaoArgs &s, bool chroma, hipStream_t stream)
+hipError_t dbk_launch_deblock_sao_h265(const DbkH265Args &h, const DbkSaoArgs &s, int sample_bytes, bool chroma, hipStream_t stream)
 {
     if (h.base.n_frames <= 0 || h.base.nbx <= 0 || h.base.nby <= 0) return hipSuccess;
     DbkFusedH265Args fa;
     fa.d = h;
     fa.s = s;
-    { /* the scalar-QP operands of the packed spec-exact kernels, as dbk_launch_packed_h265 derives them */
-        auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-        const int sh = h.base.shift, qp = h.qp;
-        fa.d.beta_s = dbk::h265_beta(cl(qp + h.beta_off, 0, 51)) << sh;
-        if (chroma) {
-            fa.d.tc_bs1 = 0;
-            fa.d.tc_bs2 = dbk::h265_tc(cl(dbk::h265_chroma_qp(qp + h.c_qp_offset) + 2 + h.tc_off, 0, 53)) << sh;
-        } else {
-            fa.d.tc_bs1 = dbk::h265_tc(cl(qp + h.tc_off, 0, 53)) << sh;
-            fa.d.tc_bs2 = dbk::h265_tc(cl(qp + 2 + h.tc_off, 0, 53)) << sh;
-        }
+    fused_h265_scalars(fa.d, chroma);
+    const dim3 grid(fused_grid(h.base.plane_w, h.base.plane_h, h.base.n_frames, sample_bytes, fa.g), 1, 1);
+    if (sample_bytes == 1) {
+        if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused_h265_kernel<true>), grid, dim3(kFusedThreads), kFusedLds, stream, fa);
+        else DBK_LAUNCH_LDS((dbk_sao_fused_h265_kernel<false>), grid, dim3(kFusedThreads), kFusedLds, stream, fa);
+    } else {
+        if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused16_h265_kernel<true, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
+        else if (h.base.max_v > 2047) DBK_LAUNCH_LDS((dbk_sao_fused16_h265_kernel<false, true>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
+        else DBK_LAUNCH_LDS((dbk_sao_fused16_h265_kernel<false, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
     }
-    const dim3 grid(fused_grid(h.base.plane_w, h.base.plane_h, h.base.n_frames, fa.g), 1, 1), block(kFusedThreads, 1, 1);
-    if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused_h265_kernel<true>), grid, block, kFusedLds, stream, fa);
-    else DBK_LAUNCH_LDS((dbk_sao_fused_h265_kernel<false>), grid, block, kFusedLds, stream, fa);
     return hipGetLastError();
 }
 
+hipError_t dbk_launch_deblock_sao_multi(const DbkArgs *d, const DbkSaoArgs *s, int n, int sample_bytes, hipStream_t stream)
+{
+    if (n < 2 || n > 3) return hipErrorInvalidValue;
+    if (d[0].n_frames <= 0) return hipSuccess;
+    DbkFusedMultiArgs m;
+    std::memset(&m, 0, sizeof(m));
+    unsigned total = 0;
+    for (int i = 0; i < 3; i++) {
+        if (i < n) {
+            m.pl[i].d = d[i];
+            m.pl[i].s = s[i];
+            total += fused_grid(d[i].plane_w, d[i].plane_h, d[i].n_frames, sample_bytes, m.pl[i].g);
+        }
+        m.wg_end[i] = total;
+    }
+    const dim3 grid(total, 1, 1);
+    if (sample_bytes == 1) DBK_LAUNCH_LDS((dbk_sao_fused_multi_kernel<1, false>), grid, dim3(kFusedThreads), kFusedLds, stream, m);
+    else if (d[0].max_v > 2047) DBK_LAUNCH_LDS((dbk_sao_fused_multi_kernel<2, true>), grid, dim3(kFused16Threads), kFused16Lds, stream, m);
+    else DBK_LAUNCH_LDS((dbk_sao_fused_multi_kernel<2, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, m);
+    return hipGetLastError();
+}
+
+hipError_t dbk_launch_deblock_sao_multi_h265(const DbkH265Args *h, const DbkSaoArgs *s, int n, int sample_bytes, hipStream_t stream)
+{
+    if (n < 2 || n > 3) return hipErrorInvalidValue;
+    if (h[0].base.n_frames <= 0) return hipSuccess;
+    DbkFusedMultiH265Args m;
+    std::memset(&m, 0, sizeof(m));
+    unsigned total = 0;
+    for (int i = 0; i < 3; i++) {
+        if (i < n) {
+            m.pl[i].d = h[i];
+            m.pl[i].s = s[i];
+            fused_h265_scalars(m.pl[i].d, i > 0);
+            total += fused_grid(h[i].base.plane_w, h[i].base.plane_h, h[i].base.n_frames, sample_bytes, m.pl[i].g);
+        }
+        m.wg_end[i] = total;
+    }
+    const dim3 grid(total, 1, 1);
+    if (sample_bytes == 1) DBK_LAUNCH_LDS((dbk_sao_fused_multi_h265_kernel<1, false>), grid, dim3(kFusedThreads), kFusedLds, stream, m);
+    else if (h[0].base.max_v > 2047) DBK_LAUNCH_LDS((dbk_sao_fused_multi_h265_kernel<2, true>), grid, dim3(kFused16Threads), kFused16Lds, stream, m);
+    else DBK_LAUNCH_LDS((dbk_sao_fused_multi_h265_kernel<2, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, m);
+    return hipGetLastError();
+}

@@ -155,3 +155,142 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
 }
 
 } /* namespace sao8 */
+
+/*
+ * 16-bit containers (bit depth 8..12): the same block procedure on samples that already are int16 pairs.  A row's eight
+ * samples are four dwords P0..P3 = (s0,s1) (s2,s3) (s4,s5) (s6,s7); the pairs shifted one sample left are L0 = (s[-1],s0),
+ * L1 = (s1,s2), L2 = (s3,s4), L3 = (s5,s6) -- one v_alignbit_b32 each -- and shifted right R0 = L1, R1 = L2, R2 = L3,
+ * R3 = (s7,s8).  Offsets travel as bytes biased by 128 exactly as in the 8-bit form (the parameter entries are int8).  Raw row = samples x-4 .. x+11 as eight dwords (two 16-byte LDS reads); d[1] holds s[-1], d[6] holds s8.
+ */
+namespace sao16 {
+
+using sao8::supk;
+using sao8::spk;
+using sao8::s_upk;
+using sao8::s_pk;
+using sao8::s_sub_sat;
+
+struct Raw {
+    uint32_t d[8];
+};
+struct Row {
+    uint32_t P0, P1, P2, P3; /* the row's samples */
+    uint32_t L0, L1, L2, L3; /* shifted one sample left; Rk = L(k+1) */
+    uint32_t R3;
+};
+template <bool HALO>
+__device__ __forceinline__ Row unpack(const Raw &q)
+{
+    Row r;
+    r.P0 = q.d[2]; r.P1 = q.d[3]; r.P2 = q.d[4]; r.P3 = q.d[5];
+    if constexpr (HALO) {
+        r.L0 = __builtin_amdgcn_alignbit(q.d[2], q.d[1], 16); /* (d1.hi, d2.lo) = (s[-1], s0) */
+        r.L1 = __builtin_amdgcn_alignbit(q.d[3], q.d[2], 16);
+        r.L2 = __builtin_amdgcn_alignbit(q.d[4], q.d[3], 16);
+        r.L3 = __builtin_amdgcn_alignbit(q.d[5], q.d[4], 16);
+        r.R3 = __builtin_amdgcn_alignbit(q.d[6], q.d[5], 16); /* (s7, s8) */
+    } else {
+        r.L0 = r.L1 = r.L2 = r.L3 = r.R3 = 0u;
+    }
+    return r;
+}
+
+struct Tab {
+    uint32_t lo, hi; /* the five offset bytes + 128 */
+    uint32_t maxv;   /* max_v in both halves */
+};
+__device__ __forceinline__ uint32_t apply(uint32_t rec, uint32_t idx, const Tab &t)
+{
+    const uint32_t o = __builtin_amdgcn_perm(t.hi, t.lo, idx | 0x0c000c00u);
+    const supk v = s_sub_sat(s_upk(rec) + s_upk(o), supk{128, 128});
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, s_upk(t.maxv)));
+}
+using sao8::edge_idx;
+
+template <int CLS, bool BORDER, typename Fetch, typename Store>
+__device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store, int x, int y0, int w, int h, const Tab &t)
+{
+    constexpr bool horizontal = CLS != 1, vertical = CLS != 0;
+    Row up = unpack<horizontal>(fetch(0)), mid = unpack<horizontal>(fetch(1)), dn;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int y = y0 + r;
+        dn = unpack<horizontal>(fetch(r + 2));
+        uint32_t i0, i1, i2, i3;
+        if constexpr (CLS == 0) {        /* (-1, 0) / (1, 0) */
+            i0 = edge_idx(mid.P0, mid.L0, mid.L1);
+            i1 = edge_idx(mid.P1, mid.L1, mid.L2);
+            i2 = edge_idx(mid.P2, mid.L2, mid.L3);
+            i3 = edge_idx(mid.P3, mid.L3, mid.R3);
+        } else if constexpr (CLS == 1) { /* (0, -1) / (0, 1) */
+            i0 = edge_idx(mid.P0, up.P0, dn.P0);
+            i1 = edge_idx(mid.P1, up.P1, dn.P1);
+            i2 = edge_idx(mid.P2, up.P2, dn.P2);
+            i3 = edge_idx(mid.P3, up.P3, dn.P3);
+        } else if constexpr (CLS == 2) { /* (-1, -1) / (1, 1) */
+            i0 = edge_idx(mid.P0, up.L0, dn.L1);
+            i1 = edge_idx(mid.P1, up.L1, dn.L2);
+            i2 = edge_idx(mid.P2, up.L2, dn.L3);
+            i3 = edge_idx(mid.P3, up.L3, dn.R3);
+        } else {                         /* (1, -1) / (-1, 1) */
+            i0 = edge_idx(mid.P0, up.L1, dn.L0);
+            i1 = edge_idx(mid.P1, up.L2, dn.L1);
+            i2 = edge_idx(mid.P2, up.L3, dn.L2);
+            i3 = edge_idx(mid.P3, up.R3, dn.L3);
+        }
+        if constexpr (BORDER) { /* a neighbour outside the picture: edgeIdx 0 (8.7.3.2) */
+            if (vertical && (y == 0 || y == h - 1)) i0 = i1 = i2 = i3 = 0x00020002u;
+            if (horizontal && x == 0) i0 = (i0 & 0xffff0000u) | 2u;              /* sample 0: low half of P0 */
+            if (horizontal && x + 8 == w) i3 = (i3 & 0x0000ffffu) | 0x00020000u; /* sample 7: high half of P3 */
+        }
+        store(r, apply(mid.P0, i0, t), apply(mid.P1, i1, t), apply(mid.P2, i2, t), apply(mid.P3, i3, t));
+        up = mid;
+        mid = dn;
+    }
+}
+
+/* one 8x8 block of 16-bit samples; fetch(i) = raw row i = image row y0 - 1 + i; store(r, four dwords) */
+template <bool BORDER, typename Fetch, typename Store>
+__device__ __forceinline__ void block(const Fetch &fetch, const Store &store, int x, int y0, int w, int h, const DbkSaoCtb &c, bool kept,
+                                      int max_v, int band_shift)
+{
+    if (kept || c.type == 0 || c.type > 2) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const Raw q = fetch(r + 1);
+            store(r, q.d[2], q.d[3], q.d[4], q.d[5]);
+        }
+        return;
+    }
+    /* the entries are SaoOffsetVal[1..4] themselves (already scaled to the bit depth by the caller, |v| <= 127): a byte biased by 128 */
+    auto b = [](int v) { return (uint32_t)(v + 128) & 0xffu; };
+    Tab t;
+    t.maxv = (uint32_t)max_v * 0x00010001u;
+    if (c.type == 1) { /* band offset: bandTable[(k + sao_band_position) & 31] = k + 1; index min(k, 4), entry 4 = no offset */
+        t.lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (b(c.offset[2]) << 16) | (b(c.offset[3]) << 24);
+        t.hi = b(0);
+        const spk pos = sao8::s_splat((int)c.cls);
+        auto band = [&](uint32_t rec) {
+            const spk k = ((s_pk(rec) >> band_shift) - pos) & sao8::s_splat(31);
+            const supk k4 = __builtin_elementwise_min(__builtin_bit_cast(supk, k), supk{4, 4});
+            return apply(rec, __builtin_bit_cast(uint32_t, k4), t);
+        };
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const Raw q = fetch(r + 1);
+            store(r, band(q.d[2]), band(q.d[3]), band(q.d[4]), band(q.d[5]));
+        }
+        return;
+    }
+    /* edge offset: index 0 -> SaoOffsetVal[1], 1 -> [2], 2 -> none, 3 -> [3], 4 -> [4] */
+    t.lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (0x80u << 16) | (b(c.offset[2]) << 24);
+    t.hi = b(c.offset[3]);
+    const int cls = c.cls & 3;
+    if (cls == 0) edge_rows<0, BORDER>(fetch, store, x, y0, w, h, t);
+    else if (cls == 1) edge_rows<1, BORDER>(fetch, store, x, y0, w, h, t);
+    else if (cls == 2) edge_rows<2, BORDER>(fetch, store, x, y0, w, h, t);
+    else edge_rows<3, BORDER>(fetch, store, x, y0, w, h, t);
+}
+
+} /* namespace sao16 */
+

@@ -342,6 +342,28 @@ class Context:
                                                      params_frame_stride, ctb_log2, keep_ptr, keep_stride, keep_frame_stride, fused,
                                                      None), self.handle)
 
+    def deblock_sao_device_planes(self, planes_list, qp, sao_list, *, h265=None, fused=_lib.FUSED_AUTO, tc_table=None, beta_table=None):
+        """hevc_deblock_sao_device_planes / hevc_deblock_sao_h265_device_planes: deblocking + SAO of Y, U, V of a batch in one
+        call (one launch where the fused kernel takes every plane).  sao_list[i] = (params_ptr, params_stride, ctb_log2) or a
+        dict with the optional params_frame_stride / keep / keep_stride / keep_frame_stride; h265 = None (reference-exact
+        deblocking) or a dict of tc_offset_div2, beta_offset_div2, cb_qp_offset, cr_qp_offset (spec-exact)."""
+        arr = (_lib.DevicePlanes * len(planes_list))(*planes_list)
+        sp = (_lib.SaoPlane * len(sao_list))()
+        for i, so in enumerate(sao_list):
+            d = so if isinstance(so, dict) else {"params": so[0], "params_stride": so[1], "ctb_log2": so[2]}
+            sp[i].params, sp[i].params_stride, sp[i].ctb_log2 = d["params"], d["params_stride"], d["ctb_log2"]
+            sp[i].params_frame_stride = d.get("params_frame_stride", 0)
+            sp[i].keep, sp[i].keep_stride, sp[i].keep_frame_stride = d.get("keep"), d.get("keep_stride", 0), d.get("keep_frame_stride", 0)
+        if h265 is None:
+            t, _k = _tables(tc_table, beta_table)
+            rc = _lib.lib().hevc_deblock_sao_device_planes(self.handle, arr, len(planes_list), int(qp), None if t is None else C.byref(t),
+                                                           sp, fused, None)
+        else:
+            prm = _lib.H265Params(h265.get("tc_offset_div2", 0), h265.get("beta_offset_div2", 0), h265.get("cb_qp_offset", 0),
+                                  h265.get("cr_qp_offset", 0))
+            rc = _lib.lib().hevc_deblock_sao_h265_device_planes(self.handle, arr, len(planes_list), int(qp), C.byref(prm), sp, fused, None)
+        _chk(rc, self.handle)
+
     def filter_device_planes(self, planes_list, qp, *, tc_table=None, beta_table=None, variant=KERNEL_AUTO):
         """hevc_deblocking_filter_device_planes: Y, U, V of a batch in one call (one fused launch where that applies)."""
         arr = (_lib.DevicePlanes * len(planes_list))(*planes_list)

@@ -398,13 +398,14 @@ HEVCDBK_API int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_devic
  * a decoder.  Operands as for hevc_deblocking_filter_device (reference-exact mode: `qp`, `tables`, the
  * planes' bS arrays) resp. hevc_deblocking_filter_h265_device (spec-exact mode: `c_idx`, `qp`, `h265_params`, the planes'
  * 4-sample-granular bS arrays) and for hevc_sao_filter_device (`params` ... `keep_frame_stride`, all DEVICE memory).
- * For 8-bit planes with a scalar QP both stages run in ONE kernel: a workgroup deblocks the offset blocks of a 192 x 128 tile
- * (plus a one-sample rim) into LDS and applies SAO from there, so every sample is read from HBM once and written once and the
- * deblocked picture never exists in memory.  Other operands (16-bit containers, QP maps) run as two launches through a
- * scratch plane owned by the context.  `fused`: HEVCDBK_FUSED_AUTO picks, _OFF forces the two launches (same bytes; for
- * A/B runs), _ON returns HEVCDBK_ERR_UNSUPPORTED where the fused kernel does not apply.  The scratch plane of the two-launch
- * form belongs to the context and is reused by the next such call: calls on one context are stream-ordered on ONE stream
- * (like every entry point, a context serves one host thread at a time).  Parity: the deblocking stage as for
+ * For 8-bit planes and for 16-bit containers up to 12 bit, with a scalar QP, both stages run in ONE kernel: a workgroup
+ * deblocks the offset blocks of a tile (8 bit: 192 x 128 samples, 16-bit containers: 128 x 128; plus a one-sample rim) into
+ * LDS and applies SAO from there, so every sample is read from HBM once and written once and the deblocked picture never
+ * exists in memory.  Other operands (QP maps, samples deeper than 12 bit) run as two launches through a scratch plane owned
+ * by the context.  `fused`: HEVCDBK_FUSED_AUTO picks, _OFF forces the two launches (same bytes; for A/B runs), _ON returns
+ * HEVCDBK_ERR_UNSUPPORTED where the fused kernel does not apply.  The scratch plane of the two-launch form belongs to the
+ * context and is reused by the next such call; its reuse is fenced by an event, so calls that hand in different streams are
+ * ordered on it (like every entry point, a context serves one host thread at a time).  Parity: the deblocking stage as for
  * its own entry points; SAO against oracle/h265_oracle.c only ("parity unpinned").
  */
 #define HEVCDBK_FUSED_AUTO 0
@@ -419,6 +420,30 @@ HEVCDBK_API int hevc_deblock_sao_h265_device(hevcdbk_context *ctx, const hevcdbk
                                              unsigned params_stride, size_t params_frame_stride, unsigned ctb_log2,
                                              const uint8_t *keep, unsigned keep_stride, size_t keep_frame_stride, int fused,
                                              void *hip_stream);
+
+/*
+ * The same for the planes of a 4:2:0 batch -- planes[0] luma, the others chroma, n_planes <= 3, one frame count -- in ONE
+ * call: where the fused kernel takes every plane (one sample width and bit depth) they go out as ONE launch, the planes'
+ * tiles one after the other in the grid; otherwise plane by plane exactly as n_planes calls of the entries above would
+ * (every plane is checked before the first launch).  sao[i] = the SAO operands of planes[i] (its own CTB grid: 4:2:0 chroma
+ * has ctb_log2 one less than luma).  Spec-exact mode: c_idx = the plane's index (0 Y, 1 Cb, 2 Cr).  The reference has
+ * neither stage after DeblockingFilter (main.cu:41-43) nor a multi-plane launch (gpu.cu:1269-1285: three launches).
+ */
+typedef struct {
+    const hevcdbk_sao_ctb *params; /* DEVICE memory */
+    unsigned params_stride;
+    size_t params_frame_stride;
+    unsigned ctb_log2;
+    const uint8_t *keep;           /* DEVICE memory, may be NULL */
+    unsigned keep_stride;
+    size_t keep_frame_stride;
+} hevcdbk_sao_plane;
+HEVCDBK_API int hevc_deblock_sao_device_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
+                                               unsigned qp, const hevcdbk_tables *tables, const hevcdbk_sao_plane *sao, int fused,
+                                               void *hip_stream);
+HEVCDBK_API int hevc_deblock_sao_h265_device_planes(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
+                                                    unsigned qp, const hevcdbk_h265_params *h265_params,
+                                                    const hevcdbk_sao_plane *sao, int fused, void *hip_stream);
 
 #ifdef __cplusplus
 }

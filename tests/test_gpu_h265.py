@@ -253,13 +253,15 @@ def test_deblock_sao_one_call(ctx, h265, oracle):
     """hevc_deblock_sao_device / hevc_deblock_sao_h265_device: deblocking followed by SAO, src -> dst, as ONE kernel (a
     workgroup deblocks the offset blocks of a 192 x 128 tile into LDS and applies SAO from there) and as two launches through
     the context's scratch plane: both equal the oracle chain SAO(deblock(x)).  Geometries around tile edges, planes smaller than a tile, luma and chroma, CTB sizes 16 / 32 / 64, keep
-    map, per-frame bS and parameters, pitched planes; 10 bit takes the two-launch form behind the same call and the fused
+    map, per-frame bS and parameters, pitched planes; 16-bit containers up to 12 bit run the fused kernel on a 128 x 128
+    tile with the packed 16-bit SAO procedure (round 3); 14 bit takes the two-launch form behind the same call and the fused
     selector refuses it."""
     from gpu_video_codec_amd import deblock, synth, _lib
     rng = np.random.RandomState(77)
     cases = [(128, 128, 8, 6, False, None), (136, 120, 8, 6, False, None), (1032, 264, 8, 6, False, 1056), (16, 8, 8, 4, False, None),
              (3840, 144, 8, 6, False, None), (264, 392, 8, 5, True, None), (1024, 128, 8, 4, True, None), (520, 136, 8, 5, False, None),
-             (256, 136, 10, 6, False, None)]
+             (256, 136, 10, 6, False, None), (136, 264, 10, 5, False, 160), (392, 136, 10, 5, True, None), (128, 128, 12, 6, False, None),
+             (1032, 136, 12, 4, True, None), (8, 16, 10, 3, True, None), (264, 136, 9, 6, False, None), (136, 136, 14, 6, False, None)]
     for (w, h, bd, ctb_log2, chroma, pitch) in cases:
         sb = 1 if bd == 8 else 2
         n = 2
@@ -281,7 +283,7 @@ def test_deblock_sao_one_call(ctx, h265, oracle):
             b.set_bs(f, *bss[f])
         want = [h265.sao_plane(oracle.filter_plane(frames[f], qp, is_chroma=chroma, bit_depth=bd, vert_bs=bss[f][0], hor_bs=bss[f][1]),
                                prm[f], ctb_log2, bit_depth=bd, keep=keep[f]) for f in range(n)]
-        modes = (_lib.FUSED_AUTO, _lib.FUSED_OFF) + ((_lib.FUSED_ON,) if bd == 8 else ())
+        modes = (_lib.FUSED_AUTO, _lib.FUSED_OFF) + ((_lib.FUSED_ON,) if bd <= 12 else ())
         for fused in modes:
             b.dst.upload(np.zeros(b.frame_bytes * n, np.uint8))
             ctx.deblock_sao_device(b.planes(), qp, dp.ptr, prm.shape[2], ctb_log2, fused=fused, **kw)
@@ -289,7 +291,7 @@ def test_deblock_sao_one_call(ctx, h265, oracle):
             for f in range(n):
                 assert np.array_equal(b.download_frame(f), want[f]), ("ref", w, h, bd, ctb_log2, chroma, fused, f)
                 assert np.array_equal(b.download_frame(f, "src"), frames[f])
-        if bd != 8:
+        if bd > 12:
             with pytest.raises(_lib.DeblockError) as e:
                 ctx.deblock_sao_device(b.planes(), qp, dp.ptr, prm.shape[2], ctb_log2, fused=_lib.FUSED_ON, **kw)
             assert e.value.code == _lib.ERR_UNSUPPORTED
@@ -314,6 +316,87 @@ def test_deblock_sao_one_call(ctx, h265, oracle):
         for x in (dp, dk, dv, dh):
             x.free()
         b.free()
+
+
+def test_deblock_sao_yuv420_one_launch(ctx, h265, oracle):
+    """hevc_deblock_sao_device_planes / hevc_deblock_sao_h265_device_planes: deblocking + SAO of Y, U and V of a 4:2:0
+    batch in ONE call -- one fused launch whose grid holds the three planes' tiles one after the other (8 bit and 10 bit) --
+    against SAO(deblock(x)) of the oracles plane by plane, both filter modes; FUSED_OFF gives the same bytes through the
+    two-launch form; a plane the fused kernel does not take (14 bit) makes FUSED_ON refuse before anything is launched."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    rng = np.random.RandomState(5)
+    for (w, h, bd, n) in ((352, 288, 8, 3), (400, 272, 10, 2), (1040, 144, 8, 1), (272, 400, 12, 2), (32, 16, 10, 1)):
+        dims = [(w, h, 6), (w // 2, h // 2, 5), (w // 2, h // 2, 5)]
+        batches, prms, wants_ref, wants_spec, dev, sao = [], [], [], [], [], []
+        qp = 35
+        spec_bs = []
+        for i, (pw, ph, cl) in enumerate(dims):
+            fr = np.stack([synth.blocky_plane(pw, ph, seed=11 * i + f + w, bit_depth=bd, dc_range=6 if i == 0 else 4) for f in range(n)])
+            fr = np.clip(fr.astype(np.int32) + rng.randint(-2, 3, fr.shape), 0, (1 << bd) - 1).astype(fr.dtype)
+            b = deblock.DeviceBatch(ctx, pw, ph, n, bit_depth=bd, is_chroma=i > 0, per_frame_bs=False)
+            b.upload_all(fr)
+            prm = h265.random_sao_params(pw, ph, cl, seed=3 * i + w, bit_depth=bd)
+            dp = ctx.alloc(prm.nbytes)
+            dp.upload(prm.view(np.uint8).ravel())
+            batches.append((b, fr))
+            dev.append(dp)
+            sao.append((dp.ptr, prm.shape[1], cl))
+            wants_ref.append([h265.sao_plane(oracle.filter_plane(fr[f], qp, is_chroma=i > 0, bit_depth=bd), prm, cl, bit_depth=bd) for f in range(n)])
+            vb = rng.randint(0, 3, h265.num_vert_bs(pw, ph)).astype(np.uint8)
+            hb = rng.randint(0, 3, h265.num_hor_bs(pw, ph)).astype(np.uint8)
+            dv, dh = ctx.alloc(vb.size), ctx.alloc(hb.size)
+            dv.upload(vb)
+            dh.upload(hb)
+            dev += [dv, dh]
+            spec_bs.append((dv, dh))
+            wants_spec.append([h265.sao_plane(h265.filter_plane(fr[f], qp, vb, hb, c_idx=i, bit_depth=bd, c_qp_offset=(0, 2, -1)[i]),
+                                              prm, cl, bit_depth=bd) for f in range(n)])
+        planes = [b.planes() for b, _ in batches]
+        for fused in (_lib.FUSED_AUTO, _lib.FUSED_ON, _lib.FUSED_OFF):
+            for b, _ in batches:
+                b.dst.upload(np.zeros(b.frame_bytes * n, np.uint8))
+            ctx.deblock_sao_device_planes(planes, qp, sao, fused=fused)
+            ctx.synchronize()
+            for i, (b, fr) in enumerate(batches):
+                for f in range(n):
+                    assert np.array_equal(b.download_frame(f), wants_ref[i][f]), ("ref", w, h, bd, fused, i, f)
+        sp = []
+        for i, (b, _) in enumerate(batches):
+            p = b.planes()
+            p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = spec_bs[i][0].ptr, spec_bs[i][1].ptr, 0, 0
+            sp.append(p)
+        for fused in (_lib.FUSED_AUTO, _lib.FUSED_ON, _lib.FUSED_OFF):
+            for b, _ in batches:
+                b.dst.upload(np.zeros(b.frame_bytes * n, np.uint8))
+            ctx.deblock_sao_device_planes(sp, qp, sao, h265=dict(cb_qp_offset=2, cr_qp_offset=-1), fused=fused)
+            ctx.synchronize()
+            for i, (b, fr) in enumerate(batches):
+                for f in range(n):
+                    assert np.array_equal(b.download_frame(f), wants_spec[i][f]), ("spec", w, h, bd, fused, i, f)
+        for b, _ in batches:
+            b.free()
+        for d in dev:
+            d.free()
+    # a plane beyond the fused kernel: FUSED_ON refuses with nothing enqueued, AUTO takes the plane-by-plane form
+    y = deblock.DeviceBatch(ctx, 64, 64, 1, bit_depth=14)
+    u = deblock.DeviceBatch(ctx, 32, 32, 1, bit_depth=14, is_chroma=True)
+    fy, fu = synth.blocky_plane(64, 64, seed=1, bit_depth=14)[None], synth.blocky_plane(32, 32, seed=2, bit_depth=14)[None]
+    y.upload_all(fy)
+    u.upload_all(fu)
+    py_, pu_ = h265.random_sao_params(64, 64, 6, seed=1, bit_depth=14), h265.random_sao_params(32, 32, 5, seed=2, bit_depth=14)
+    d1, d2 = ctx.alloc(py_.nbytes), ctx.alloc(pu_.nbytes)
+    d1.upload(py_.view(np.uint8).ravel())
+    d2.upload(pu_.view(np.uint8).ravel())
+    so = [(d1.ptr, py_.shape[1], 6), (d2.ptr, pu_.shape[1], 5)]
+    with pytest.raises(_lib.DeblockError) as e:
+        ctx.deblock_sao_device_planes([y.planes(), u.planes()], 30, so, fused=_lib.FUSED_ON)
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    ctx.deblock_sao_device_planes([y.planes(), u.planes()], 30, so)
+    ctx.synchronize()
+    assert np.array_equal(y.download_frame(0), h265.sao_plane(oracle.filter_plane(fy[0], 30, bit_depth=14), py_, 6, bit_depth=14))
+    assert np.array_equal(u.download_frame(0), h265.sao_plane(oracle.filter_plane(fu[0], 30, is_chroma=True, bit_depth=14), pu_, 5, bit_depth=14))
+    for x in (y, u, d1, d2):
+        x.free()
 
 
 def test_random_geometry_sweep_both_modes(ctx, h265, oracle):
