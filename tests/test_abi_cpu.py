@@ -23,7 +23,7 @@ def L():
 def test_exports_match_header(L):
     from gpu_video_codec_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "hevc_deblock.h")).read()
-    declared = set(re.findall(r"\b(hevcdbk_[a-z0-9_]+|hevc_sao_filter_device|hevc_deblock_sao(?:_h265)?_device|hevc_deblocking_filter(?:_h265_device|_h265|_device_planes|_device|_sequence)?)\s*\(", hdr))
+    declared = set(re.findall(r"\b(hevcdbk_[a-z0-9_]+|hevc_sao_filter_device|hevc_deblock_sao(?:_h265)?_device(?:_planes)?|hevc_deblocking_filter(?:_h265_device|_h265|_device_planes|_device|_sequence)?)\s*\(", hdr))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for s in declared:
         assert hasattr(L, s), s
