@@ -318,6 +318,29 @@ def test_deblock_sao_one_call(ctx, h265, oracle):
         b.free()
 
 
+def test_deblock_sao_16bit_4k_repeated(ctx, h265, oracle):
+    """The fused kernel for 16-bit containers on whole 4K frames, several launches in a row: round 3 found a few hundred wrong
+    samples per frame in the FIRST launch of a process only (a 16-byte buffer store's data overwritten by the VALU right
+    behind it while the card was still at its idle clock); the kernel now keeps two wait states there."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    w, h, n, bd = 3840, 2160, 2, 10
+    fr = np.stack([synth.blocky_plane(w, h, seed=9, frame=i, bit_depth=bd) for i in range(n)])
+    b = deblock.DeviceBatch(ctx, w, h, n, bit_depth=bd, per_frame_bs=False)
+    b.upload_all(fr)
+    prm = h265.random_sao_params(w, h, 6, seed=19, bit_depth=bd)
+    d = ctx.alloc(prm.nbytes)
+    d.upload(prm.view(np.uint8).ravel())
+    want = [h265.sao_plane(oracle.filter_plane(fr[f], 32, bit_depth=bd, threads=8), prm, 6, bit_depth=bd) for f in range(n)]
+    for it in range(4):
+        b.dst.upload(np.zeros(b.frame_bytes * n, np.uint8))
+        ctx.deblock_sao_device(b.planes(), 32, d.ptr, prm.shape[1], 6, fused=_lib.FUSED_ON)
+        ctx.synchronize()
+        for f in range(n):
+            assert np.array_equal(b.download_frame(f), want[f]), (it, f)
+    b.free()
+    d.free()
+
+
 def test_deblock_sao_yuv420_one_launch(ctx, h265, oracle):
     """hevc_deblock_sao_device_planes / hevc_deblock_sao_h265_device_planes: deblocking + SAO of Y, U and V of a 4:2:0
     batch in ONE call -- one fused launch whose grid holds the three planes' tiles one after the other (8 bit and 10 bit) --
