@@ -95,19 +95,19 @@ def main():
                 if b.qp_map is not None:
                     b.qp_map.free()
                 b.free()
-        # 8-bit scalar-QP cases also through deblocking + SAO in one kernel (and as two launches), both filter modes
-        if bd == 8 and not use_map and not in_place:
+        # scalar-QP cases up to 12 bit also through deblocking + SAO in one kernel (and as two launches), both filter modes
+        if bd <= 12 and not use_map and not in_place:
             ctb_log2 = int(rng.choice([3, 4, 5, 6]))
-            prm = np.stack([h265.random_sao_params(w, h, ctb_log2, seed=int(rng.randint(1, 1 << 30))) for _ in range(n)])
+            prm = np.stack([h265.random_sao_params(w, h, ctb_log2, seed=int(rng.randint(1, 1 << 30)), bit_depth=bd) for _ in range(n)])
             keep = (rng.randint(0, 5, (n, h // 8, w // 8)) == 0).astype(np.uint8)
             dp, dk = ctx.alloc(prm.nbytes), ctx.alloc(keep.nbytes)
             dp.upload(prm.view(np.uint8).ravel())
             dk.upload(keep.ravel())
             kw = dict(params_frame_stride=prm.shape[1] * prm.shape[2], keep_ptr=dk.ptr, keep_stride=w // 8, keep_frame_stride=(h // 8) * (w // 8))
-            b = deblock.DeviceBatch(ctx, w, h, n, is_chroma=chroma, per_frame_bs=False)
+            b = deblock.DeviceBatch(ctx, w, h, n, bit_depth=bd, is_chroma=chroma, per_frame_bs=False)
             b.upload_all(frames)
             b.set_bs(0, rvb, rhb)
-            want = [h265.sao_plane(want_ref[f], prm[f], ctb_log2, keep=keep[f]) for f in range(n)]
+            want = [h265.sao_plane(want_ref[f], prm[f], ctb_log2, bit_depth=bd, keep=keep[f]) for f in range(n)]
             for fused in (_lib.FUSED_ON, _lib.FUSED_OFF):
                 ctx.deblock_sao_device(b.planes(), qp, dp.ptr, prm.shape[2], ctb_log2, fused=fused, **kw)
                 ctx.synchronize()
@@ -120,7 +120,7 @@ def main():
             dh.upload(hb)
             p = b.planes()
             p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
-            want = [h265.sao_plane(want_spec[f], prm[f], ctb_log2, keep=keep[f]) for f in range(n)]
+            want = [h265.sao_plane(want_spec[f], prm[f], ctb_log2, bit_depth=bd, keep=keep[f]) for f in range(n)]
             for fused in (_lib.FUSED_ON, _lib.FUSED_OFF):
                 ctx.deblock_sao_h265_device(p, qp_s, dp.ptr, prm.shape[2], ctb_log2, c_idx=1 if chroma else 0, cb_qp_offset=cq, fused=fused, **offs, **kw)
                 ctx.synchronize()
