@@ -411,7 +411,16 @@ template <bool ALL_ON, bool HAVE_T = false, class K>
 DBK_HD NormalD normal_deltas(const Taps &t, pk delta, const K &k, pk tp = pk{0, 0}, pk tq = pk{0, 0})
 {
     NormalD n;
-    n.D = pk_min(pk_max(delta, k.nnegc()), k.nc());
+    pk on = pk{0, 0};
+    if constexpr (ALL_ON) {
+        n.D = pk_min(pk_max(delta, k.nnegc()), k.nc());
+    } else {
+        /* all ones where |delta| < 10*tc (cpu.h:1254).  The mask goes onto delta BEFORE the clip (clip(0) = 0): written as
+         * clip(delta) & on, the clip is an expression both forms share, the compiler hoists it ahead of the branch, and the
+         * unmasked form then pays a register copy at the join (one v_mov per segment in the path every wave takes) */
+        on = (pk_abs(delta) - k.nlim()) >> 15;
+        n.D = pk_min(pk_max(delta & on, k.nnegc()), k.nc());
+    }
     /* (((p2+p0+1)>>1) - p1 + D) >> 1  ==  (p2 + p0 + 1 - 2*p1 + 2*D) >> 2   (floor of a floor: the dropped
      * bit of the inner shift is worth 1/4 and cannot carry across an integer).  HAVE_T: p2 + p0 + 1 - 2*p1 (and the Q twin)
      * of this pair is already there from the decisions (pair A) */
@@ -426,8 +435,6 @@ DBK_HD NormalD normal_deltas(const Taps &t, pk delta, const K &k, pk tp = pk{0, 
     n.dp1 = pk_min(pk_max(mad_k<2>(n.D, ip) >> 2, k.nnegc2()), k.nc2());
     n.dq1 = pk_min(pk_max(mad_k<-2>(n.D, iq) >> 2, k.nnegc2()), k.nc2());
     if constexpr (!ALL_ON) {
-        const pk on = (pk_abs(delta) - k.nlim()) >> 15; /* all ones where |delta| < 10*tc (cpu.h:1254) */
-        n.D = n.D & on;
         n.dp1 = n.dp1 & on;
         n.dq1 = n.dq1 & on;
     }

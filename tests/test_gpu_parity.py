@@ -220,6 +220,32 @@ def test_config3_image2_random_bs_and_ctu_qp_map(ctx, oracle, golden_inputs):
     assert np.array_equal(uu, oracle.filter_plane(u, 0, is_chroma=True, qp_map=qmap))
 
 
+def test_qp_map_with_lane_varying_tc_on_flat_content(ctx, oracle):
+    """with a per-CTU QP map the strong filter's clip range (2*tc) differs from lane to lane inside one wave,
+    and its three-operand add takes -c as a VECTOR operand there (an SGPR constraint on a divergent value could be legalised
+    with v_readfirstlane: lane 0's tc for every lane).  Flat content so that nearly every segment is strong-filtered, an
+    8x8 / 16x16 CTU map so that neighbouring lanes hold different QPs, 8 and 10 bit, every kernel family."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    rng = np.random.RandomState(31)
+    for (w, h, bd, ctu_log2) in ((1024, 64, 8, 3), (1032, 72, 8, 4), (520, 136, 10, 3), (4096, 16, 8, 3)):
+        xx, yy = np.meshgrid(np.arange(w), np.arange(h))
+        flat = (100 + 40 * np.sin(xx / 180.0) + 0.05 * yy) * (1 << (bd - 8))
+        steps = np.repeat(np.repeat(rng.randint(-3, 4, (h // 8, w // 8)), 8, 0), 8, 1) * (1 << (bd - 8))   # small block steps: strong filter
+        plane = np.clip(flat + steps, 0, (1 << bd) - 1).astype(np.uint8 if bd == 8 else np.uint16)
+        qmap = rng.randint(30, 52, ((h + (1 << ctu_log2) - 1) >> ctu_log2, (w + (1 << ctu_log2) - 1) >> ctu_log2)).astype(np.uint8)
+        want = oracle.filter_plane(plane, 0, bit_depth=bd, qp_map=qmap, ctu_log2=ctu_log2)
+        assert (want != plane).mean() > 0.2   # the content does get filtered
+        for variant in (_lib.KERNEL_GENERIC, _lib.KERNEL_PACKED, _lib.KERNEL_AUTO):
+            b = deblock.DeviceBatch(ctx, w, h, 1, bit_depth=bd)
+            b.upload_all(plane[None])
+            b.set_qp_map(qmap, ctu_log2)
+            ctx.filter_device(b.planes(), 0, variant=variant)
+            ctx.synchronize()
+            assert np.array_equal(b.download_frame(0), want), (w, h, bd, ctu_log2, variant)
+            b.qp_map.free()
+            b.free()
+
+
 def test_custom_tables(ctx, oracle, golden_inputs):
     y, _, _ = oracle.split_yuv420(golden_inputs["image1"], 352, 288)
     tc, beta = oracle.tables()
