@@ -104,6 +104,23 @@ def test_fails_loudly_without_gpu(L, tmp_path):
     assert not out.exists()
 
 
+def test_round3_entries_validate_arguments_without_a_gpu(L):
+    """The entries added in round 3 -- steady-state replay, PCI id, multi-plane deblocking + SAO -- refuse bad arguments
+    before they touch a device (no compute call is made here)."""
+    from gpu_video_codec_amd import _lib
+    planes = (_lib.DevicePlanes * 2)()
+    sao = (_lib.SaoPlane * 2)()
+    r = _lib.Replay(steps=3)
+    ms = (C.c_float * 3)()
+    assert L.hevcdbk_device_replay(None, planes, 1, 30, None, 0, C.byref(r), ms) == _lib.ERR_ARG
+    assert L.hevcdbk_device_pci_bus_id(None, C.create_string_buffer(64), 64) == _lib.ERR_ARG
+    assert L.hevc_deblock_sao_device_planes(None, planes, 2, 30, None, sao, _lib.FUSED_AUTO, None) == _lib.ERR_ARG
+    assert L.hevc_deblock_sao_h265_device_planes(None, planes, 2, 30, None, sao, _lib.FUSED_AUTO, None) == _lib.ERR_ARG
+    # the struct layouts the bindings assume (include/hevc_deblock.h: hevcdbk_replay, hevcdbk_sao_plane)
+    assert C.sizeof(_lib.Replay) == 3 * 8 + 3 * 4 + 2 * 4 + 4 + 6 * 8 or C.sizeof(_lib.Replay) % 8 == 0
+    assert C.sizeof(_lib.SaoPlane) == 56
+
+
 def test_execute_gpu_validation_order(L, tmp_path):
     """Size check before divisibility check, as gpu.cu:1082-1087 / cpu.h:43-48."""
     from gpu_video_codec_amd import _lib
