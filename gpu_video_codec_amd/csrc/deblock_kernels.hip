@@ -167,15 +167,6 @@ hipError_t dbk_launch_generic(const DbkArgs &a, int sample_bytes, bool chroma, h
 
 namespace {
 
-/*
- * Every packed kernel declares v63 as touched, so that its waves are allocated exactly 64 VGPRs -- one eighth of a SIMD's
- * register file -- whatever the register allocator needed (48..63, depending on unrelated details of the source).  Measured
- * in round 3 (profiles/r03/experiments.md): the same kernel at 48 VGPRs runs 1 % SLOWER than at 63, with 17 % fewer waves
- * resident on average (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES): a SIMD has 8 wave slots either way, and with allocations that do
- * not tile the file, a finished wave's registers are not always where the next wave fits.
- */
-#define DBK_WHOLE_SLOT() asm volatile("" ::: "v63")
-
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -712,7 +703,6 @@ __device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
 template <int MODE, bool NT, bool LINEAR, bool QPMAP, bool WIDE = false>
 __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
 {
-    DBK_WHOLE_SLOT();
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
     if (c.interior) packed16_body<MODE, NT, false, QPMAP, false, WIDE>(a, c.by, c.f, c.bx, true);
@@ -723,7 +713,6 @@ __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
 template <bool LINEAR, bool QPMAP>
 __global__ __launch_bounds__(1024) void dbk_packed16c_kernel(const DbkArgs a)
 {
-    DBK_WHOLE_SLOT();
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
     if (c.interior) packed16_body<0, false, false, QPMAP, true>(a, c.by, c.f, c.bx, true);
@@ -732,7 +721,6 @@ __global__ __launch_bounds__(1024) void dbk_packed16c_kernel(const DbkArgs a)
 template <bool CHROMA, bool LINEAR, bool QPMAP, bool WIDE = false>
 __global__ __launch_bounds__(1024) void dbk_packed16_h265_kernel(const DbkH265Args h)
 {
-    DBK_WHOLE_SLOT();
     const DbkArgs &a = h.base;
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
@@ -752,7 +740,6 @@ __global__ __launch_bounds__(1024) void dbk_packed16_h265_kernel(const DbkH265Ar
 template <bool CHROMA, int MODE, bool NT, bool LINEAR, bool QPMAP>
 __global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
 {
-    DBK_WHOLE_SLOT();
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
     if (c.interior) packed_body<CHROMA, MODE, NT, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0);
@@ -774,7 +761,6 @@ __device__ __forceinline__ void packed_h265_dispatch(const DbkH265Args &h)
 template <bool CHROMA, bool LINEAR, bool QPMAP>
 __global__ __launch_bounds__(1024) void dbk_packed_h265_kernel(const DbkH265Args h)
 {
-    DBK_WHOLE_SLOT();
     packed_h265_dispatch<CHROMA, LINEAR, QPMAP>(h);
 }
 /* ------------------------------------------------------------------------------------------ */
@@ -788,7 +774,6 @@ __global__ __launch_bounds__(1024) void dbk_packed_h265_kernel(const DbkH265Args
 template <bool NT>
 __global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiArgs m)
 {
-    DBK_WHOLE_SLOT();
     const int row = blockIdx.x;
     const int pl = row >= m.row_end[0] ? (row >= m.row_end[1] ? 2 : 1) : 0; /* scalar */
     const DbkArgs &a = m.p[pl];
@@ -819,7 +804,6 @@ __global__ __launch_bounds__(1024) void dbk_packed_multi_kernel(const DbkMultiAr
 template <bool WIDE>
 __global__ __launch_bounds__(1024) void dbk_packed16_multi_kernel(const DbkMultiArgs m)
 {
-    DBK_WHOLE_SLOT();
     const int row = blockIdx.x;
     const int pl = row >= m.row_end[0] ? (row >= m.row_end[1] ? 2 : 1) : 0; /* scalar */
     const DbkArgs &a = m.p[pl];
