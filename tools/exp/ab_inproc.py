@@ -29,7 +29,9 @@ from gpu_video_codec_amd import synth  # noqa: E402
 class Lib:
     def __init__(self, name, path, variant, diag=None):
         self.name, self.path = name, path
-        self.variant = {"auto": 0, "packed": 2, "copy": 100}[variant]
+        fam, _, mp = variant.partition("+")   # e.g. "auto+linear", "copy+group" (the maps beyond rows / linear: diagnostic library)
+        self.variant = {"auto": 0, "packed": 2, "copy": 100}[fam or "auto"]
+        self.map_bits = {"": 0, "rows": 0x100, "linear": 0x200, "stripe": 0x300, "tiles": 0x400, "pipe": 0x500, "group": 0x600}[mp]
         self.L = C.CDLL(os.path.abspath(path), mode=os.RTLD_LOCAL | os.RTLD_NOW)
         self.L.hevcdbk_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         self.L.hevcdbk_destroy.argtypes = [C.c_void_p]
@@ -63,7 +65,7 @@ class Lib:
         ms = (C.c_float * steps)()
         if self.has_replay:
             r = L0.Replay(settle_min_ms=settle_ms, settle_max_ms=settle_ms, warmup=3, steps=steps)
-            rc = self.L.hevcdbk_device_replay(self.h, arr, 1, qp, None, self.variant, C.byref(r), ms)
+            rc = self.L.hevcdbk_device_replay(self.h, arr, 1, qp, None, self.variant | self.map_bits, C.byref(r), ms)
         else:
             n = max(int(settle_ms / 0.8), 1)
             tmp = (C.c_float * n)()
