@@ -3,6 +3,7 @@ include/hevc_deblock.h, its host-only helpers agree with the oracle, and -- with
 compute entry point fails loudly instead of falling back to a CPU path."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -257,3 +258,14 @@ def test_reference_driver_links_against_the_library(tmp_path):
         assert run.returncode == 0 and sha256(gpu_out.read_bytes()) == sha256(cpu_out.read_bytes())
     else:
         assert run.returncode != 0 and not gpu_out.exists()   # fails loudly: there is no CPU path in the library
+
+
+def test_no_wide_store_is_overwritten_in_its_shadow():
+    """Round 3 found a 16-byte buffer store whose data registers the very next VALU instruction overwrote (legal by the
+    compiler's hazard table when soffset is an SGPR; on MI355X the first launch of a process wrote garbage).  The scanner
+    compiles the product's three .hip files to ISA and looks for any 12- / 16-byte store followed within two issue slots by a
+    VALU write to its data registers."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_hazard.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "0 suspicious" in r.stdout
