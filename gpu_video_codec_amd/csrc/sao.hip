@@ -264,9 +264,9 @@ __device__ __forceinline__ void sao8_edge_block(const DbkSaoArgs &a, const uint8
             i3 = sao_edge_idx(mid.O1, up.rO1, dn.E1);
         }
         if constexpr (BORDER) { /* a neighbour outside the picture: edgeIdx 0 (8.7.3.2) */
-            if (vertical && (y == 0 || y == a.plane_h - 1)) i0 = i1 = i2 = i3 = 0x00020002u;
-            if (horizontal && x == 0) i0 = (i0 & 0xffff0000u) | 2u;                       /* sample 0: low half of E0 */
-            if (horizontal && x + 8 == a.plane_w) i3 = (i3 & 0x0000ffffu) | 0x00020000u;  /* sample 7: high half of O1 */
+            if (vertical && (y == 0 || y == a.plane_h - 1)) i0 = i1 = i2 = i3 = 0x00020002u | sao8::kSel;
+            if (horizontal && x == 0) i0 = (i0 & 0xffff0000u) | 0x0c02u;                       /* sample 0: low half of E0 */
+            if (horizontal && x + 8 == a.plane_w) i3 = (i3 & 0x0000ffffu) | 0x0c020000u;  /* sample 7: high half of O1 */
         }
         const uint32_t e0 = sao_apply(mid.E0, i0, tab_lo, tab_hi), o0 = sao_apply(mid.O0, i1, tab_lo, tab_hi);
         const uint32_t e1 = sao_apply(mid.E1, i2, tab_lo, tab_hi), o1 = sao_apply(mid.O1, i3, tab_lo, tab_hi);
@@ -279,13 +279,13 @@ __device__ __forceinline__ void sao8_edge_block(const DbkSaoArgs &a, const uint8
     }
 }
 
-template <bool SWZ>
-__global__ __launch_bounds__(256) void sao8_kernel(const DbkSaoArgs a, const DbkFusedGrid g)
+template <bool SWZ, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void sao8_kernel(const DbkSaoArgs a, const DbkFusedGrid g)
 {
     int wx, wy, f;
     if (!sao_strip<SWZ>(g, wx, wy, f)) return;
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int x = (wx * 4 + wv) * 64 + (l & 7) * 8;
+    const int x = (wx * WAVES + wv) * 64 + (l & 7) * 8;
     const int y0 = wy * 64 + (l >> 3) * 8;
     if (x >= a.plane_w || y0 >= a.plane_h) return;
     const uint8_t *src = a.src + (long long)f * a.frame_stride;
@@ -304,9 +304,7 @@ __global__ __launch_bounds__(256) void sao8_kernel(const DbkSaoArgs a, const Dbk
         const uint32_t tab_lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (b(c.offset[2]) << 16) | (b(c.offset[3]) << 24), tab_hi = b(0);
         const spk pos = s_splat((int)c.cls);
         auto band = [&](uint32_t rec) {
-            const spk k = ((s_pk(rec) >> 3) - pos) & s_splat(31);              /* 8 bit: bandShift = bitDepth - 5 = 3 */
-            const supk k4 = __builtin_elementwise_min(__builtin_bit_cast(supk, k), supk{4, 4});
-            return sao_apply(rec, __builtin_bit_cast(uint32_t, k4), tab_lo, tab_hi);
+            return sao_apply(rec, sao8::band_sel(rec, 3, pos), tab_lo, tab_hi); /* 8 bit: bandShift = bitDepth - 5 = 3 */
         };
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -330,7 +328,15 @@ __global__ __launch_bounds__(256) void sao8_kernel(const DbkSaoArgs a, const Dbk
 hipError_t dbk_launch_sao(const DbkSaoArgs &a, int sample_bytes, hipStream_t stream)
 {
     if (a.n_frames <= 0 || a.plane_w <= 0 || a.plane_h <= 0) return hipSuccess;
-    const dim3 block(256, 1, 1), grid3((a.plane_w + 255) / 256, (a.plane_h + 63) / 64, a.n_frames);
+    int waves = 4; /* 64 x 64 regions (waves) side by side in one workgroup */
+#ifdef HEVCDBK_DIAG
+    if (g_dbk_diag.wg_cap == 64 || g_dbk_diag.wg_cap == 128) waves = g_dbk_diag.wg_cap / 64; /* A/B knob: narrower workgroups of the packed 8-bit kernel */
+#endif
+    const bool aligned8 = a.pitch % 8 == 0 && a.frame_stride % 8 == 0 && ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0 &&
+                          a.plane_w % 8 == 0 && a.plane_h % 8 == 0 && a.max_v == 255 && a.band_shift == 3;
+    if (!(sample_bytes == 1 && aligned8)) waves = 4;
+    const int strip_w = 64 * waves;
+    const dim3 block(strip_w, 1, 1), grid3((a.plane_w + strip_w - 1) / strip_w, (a.plane_h + 63) / 64, a.n_frames);
     /* the renumbered 1-D grid (sao_strip): strips per frame and in total small enough for exact reciprocal division
      * (dividend < 2^32 / divisor) */
     DbkFusedGrid g = {};
@@ -349,11 +355,14 @@ hipError_t dbk_launch_sao(const DbkSaoArgs &a, int sample_bytes, hipStream_t str
     }
     const dim3 grid = swz ? dim3(g.per_xcd * 8u, 1, 1) : grid3;
     /* 8-bit planes whose rows and frames are 8-byte aligned take the packed kernel (every lane moves 8 bytes at once) */
-    const bool aligned8 = a.pitch % 8 == 0 && a.frame_stride % 8 == 0 && ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0 &&
-                          a.plane_w % 8 == 0 && a.plane_h % 8 == 0 && a.max_v == 255 && a.band_shift == 3;
     if (sample_bytes == 1 && aligned8) {
-        if (swz) hipLaunchKernelGGL(sao8_kernel<true>, grid, block, 0, stream, a, g);
-        else hipLaunchKernelGGL(sao8_kernel<false>, grid, block, 0, stream, a, g);
+#ifdef HEVCDBK_DIAG
+        if (waves == 1 && swz) hipLaunchKernelGGL((sao8_kernel<true, 1>), grid, block, 0, stream, a, g);
+        else if (waves == 2 && swz) hipLaunchKernelGGL((sao8_kernel<true, 2>), grid, block, 0, stream, a, g);
+        else
+#endif
+        if (swz) hipLaunchKernelGGL((sao8_kernel<true, 4>), grid, block, 0, stream, a, g);
+        else hipLaunchKernelGGL((sao8_kernel<false, 4>), grid, block, 0, stream, a, g);
     } else if (sample_bytes == 1) {
         if (swz) hipLaunchKernelGGL((sao_kernel<uint8_t, true>), grid, block, 0, stream, a, g);
         else hipLaunchKernelGGL((sao_kernel<uint8_t, false>), grid, block, 0, stream, a, g);

@@ -50,21 +50,38 @@ __device__ __forceinline__ supk s_upk(uint32_t v) { return __builtin_bit_cast(su
 /* max(a - b, 0) in both halves: ONE v_pk_sub_u16 with the clamp bit (unsigned saturation) */
 __device__ __forceinline__ supk s_sub_sat(supk a, supk b) { return __builtin_elementwise_sub_sat(a, b); }
 
-/* rec + offset[index], clipped to 8 bit: tab_lo / tab_hi hold the five offset bytes + 128.  rec + t is non-negative, so
- * the lower clip is the saturation of the unsigned subtraction of the bias */
-__device__ __forceinline__ uint32_t apply(uint32_t rec, uint32_t idx, uint32_t tab_lo, uint32_t tab_hi)
+/* a table index (0..4) in each half as a v_perm_b32 selector: byte 0 / 2 = the index, byte 1 / 3 = 0x0c (constant zero) */
+constexpr uint32_t kSel = 0x0c000c00u;
+
+/* rec + offset[index], clipped to 8 bit: tab_lo / tab_hi hold the five offset bytes + 128, `sel` = the indices of both
+ * halves + kSel.  rec + t is non-negative, so the lower clip is the saturation of the unsigned subtraction of the bias */
+__device__ __forceinline__ uint32_t apply(uint32_t rec, uint32_t sel, uint32_t tab_lo, uint32_t tab_hi)
 {
-    const uint32_t t = __builtin_amdgcn_perm(tab_hi, tab_lo, idx | 0x0c000c00u);
+    const uint32_t t = __builtin_amdgcn_perm(tab_hi, tab_lo, sel);
     const supk v = s_sub_sat(s_upk(rec) + s_upk(t), supk{128, 128});
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, supk{255, 255}));
 }
-/* edge index of both samples of `rec` against the neighbour pairs a and b: 0..4, 2 = neither minimum nor maximum;
+/* edge index of both samples of `rec` against the neighbour pairs a and b, as a selector (+ kSel): 0..4, 2 = neither minimum nor maximum;
  * clamp(rec + 1 - a, 0, 2) = min(saturating (rec + 1) - a, 2) */
 __device__ __forceinline__ uint32_t edge_idx(uint32_t rec, uint32_t a, uint32_t b)
 {
     const supk r1 = s_upk(rec) + supk{1, 1}, two = supk{2, 2};
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(s_sub_sat(r1, s_upk(a)), two) +
-                                            __builtin_elementwise_min(s_sub_sat(r1, s_upk(b)), two));
+    /* the halves hold 0..2 each: the sum and the selector constant are ONE 32-bit three-operand add (written out: hipcc sees
+     * that no bits overlap, turns the second add into an OR with a literal and then cannot merge the two) */
+    uint32_t r;
+    asm("v_add3_u32 %0, %1, %2, %3"
+        : "=v"(r)
+        : "v"(__builtin_bit_cast(uint32_t, __builtin_elementwise_min(s_sub_sat(r1, s_upk(a)), two))),
+          "v"(__builtin_bit_cast(uint32_t, __builtin_elementwise_min(s_sub_sat(r1, s_upk(b)), two))), "s"(kSel));
+    return r;
+}
+/* band index of both samples of `rec` as a selector: min(((rec >> shift) - pos) & 31, 4) + kSel, the constant OR-ed in by
+ * the mask instruction (v_and_or_b32, written out for the same reason) and carried through the minimum */
+__device__ __forceinline__ uint32_t band_sel(uint32_t rec, int shift, spk pos)
+{
+    uint32_t k;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(k) : "v"(__builtin_bit_cast(uint32_t, (s_pk(rec) >> shift) - pos)), "s"(0x001f001fu), "v"(kSel));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(s_upk(k), s_upk(kSel | 0x00040004u)));
 }
 
 /* the 8 output rows of an edge-offset block from its ten raw rows, class CLS of Table 8-13: 0 (-1,0)/(1,0); 1 (0,-1)/(0,1);
@@ -104,9 +121,9 @@ __device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store
             i3 = edge_idx(mid.O1, up.rO1, dn.E1);
         }
         if constexpr (BORDER) {
-            if (vertical && (y == 0 || y == h - 1)) i0 = i1 = i2 = i3 = 0x00020002u;
-            if (horizontal && x == 0) i0 = (i0 & 0xffff0000u) | 2u;              /* sample 0: low half of E0 */
-            if (horizontal && x + 8 == w) i3 = (i3 & 0x0000ffffu) | 0x00020000u; /* sample 7: high half of O1 */
+            if (vertical && (y == 0 || y == h - 1)) i0 = i1 = i2 = i3 = 0x00020002u | sao8::kSel;
+            if (horizontal && x == 0) i0 = (i0 & 0xffff0000u) | 0x0c02u;              /* sample 0: low half of E0 */
+            if (horizontal && x + 8 == w) i3 = (i3 & 0x0000ffffu) | 0x0c020000u; /* sample 7: high half of O1 */
         }
         const uint32_t e0 = apply(mid.E0, i0, tab_lo, tab_hi), o0 = apply(mid.O0, i1, tab_lo, tab_hi);
         const uint32_t e1 = apply(mid.E1, i2, tab_lo, tab_hi), o1 = apply(mid.O1, i3, tab_lo, tab_hi);
@@ -134,9 +151,7 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
         const uint32_t tab_lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (b(c.offset[2]) << 16) | (b(c.offset[3]) << 24), tab_hi = b(0);
         const spk pos = s_splat((int)c.cls);
         auto band = [&](uint32_t rec) {
-            const spk k = ((s_pk(rec) >> 3) - pos) & s_splat(31); /* 8 bit: bandShift = bitDepth - 5 = 3 */
-            const supk k4 = __builtin_elementwise_min(__builtin_bit_cast(supk, k), supk{4, 4});
-            return apply(rec, __builtin_bit_cast(uint32_t, k4), tab_lo, tab_hi);
+            return apply(rec, band_sel(rec, 3, pos), tab_lo, tab_hi); /* 8 bit: bandShift = bitDepth - 5 = 3 */
         };
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -199,9 +214,9 @@ struct Tab {
     uint32_t lo, hi; /* the five offset bytes + 128 */
     uint32_t maxv;   /* max_v in both halves */
 };
-__device__ __forceinline__ uint32_t apply(uint32_t rec, uint32_t idx, const Tab &t)
+__device__ __forceinline__ uint32_t apply(uint32_t rec, uint32_t idx /* + sao8::kSel */, const Tab &t)
 {
-    const uint32_t o = __builtin_amdgcn_perm(t.hi, t.lo, idx | 0x0c000c00u);
+    const uint32_t o = __builtin_amdgcn_perm(t.hi, t.lo, idx);
     const supk v = s_sub_sat(s_upk(rec) + s_upk(o), supk{128, 128});
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, s_upk(t.maxv)));
 }
@@ -239,9 +254,9 @@ __device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store
             i3 = edge_idx(mid.P3, up.R3, dn.L3);
         }
         if constexpr (BORDER) { /* a neighbour outside the picture: edgeIdx 0 (8.7.3.2) */
-            if (vertical && (y == 0 || y == h - 1)) i0 = i1 = i2 = i3 = 0x00020002u;
-            if (horizontal && x == 0) i0 = (i0 & 0xffff0000u) | 2u;              /* sample 0: low half of P0 */
-            if (horizontal && x + 8 == w) i3 = (i3 & 0x0000ffffu) | 0x00020000u; /* sample 7: high half of P3 */
+            if (vertical && (y == 0 || y == h - 1)) i0 = i1 = i2 = i3 = 0x00020002u | sao8::kSel;
+            if (horizontal && x == 0) i0 = (i0 & 0xffff0000u) | 0x0c02u;              /* sample 0: low half of P0 */
+            if (horizontal && x + 8 == w) i3 = (i3 & 0x0000ffffu) | 0x0c020000u; /* sample 7: high half of P3 */
         }
         store(r, apply(mid.P0, i0, t), apply(mid.P1, i1, t), apply(mid.P2, i2, t), apply(mid.P3, i3, t));
         up = mid;
@@ -271,9 +286,7 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
         t.hi = b(0);
         const spk pos = sao8::s_splat((int)c.cls);
         auto band = [&](uint32_t rec) {
-            const spk k = ((s_pk(rec) >> band_shift) - pos) & sao8::s_splat(31);
-            const supk k4 = __builtin_elementwise_min(__builtin_bit_cast(supk, k), supk{4, 4});
-            return apply(rec, __builtin_bit_cast(uint32_t, k4), t);
+            return apply(rec, sao8::band_sel(rec, band_shift, pos), t);
         };
 #pragma unroll
         for (int r = 0; r < 8; r++) {
