@@ -361,7 +361,7 @@ int hevc_deblock_sao_device_planes(hevcdbk_context *ctx, const hevcdbk_device_pl
         if (int rc = planes_to_args(&planes[i], qp, tables, da[i])) return rc;
         if (planes[i].n_frames != planes[0].n_frames) return HEVCDBK_ERR_ARG;
         one = one && (i == 0 || planes[i].is_chroma) && planes[i].sample_bytes == planes[0].sample_bytes &&
-              planes[i].bit_depth == planes[0].bit_depth &&
+              planes[i].bit_depth == planes[0].bit_depth && (da[i].qp_map != nullptr) == (da[0].qp_map != nullptr) &&
               dbk_deblock_sao_supports(da[i], sa[i], (int)planes[i].sample_bytes, planes[i].is_chroma != 0);
     }
     if (int rc = bind(ctx)) return rc;
@@ -397,7 +397,7 @@ int hevc_deblock_sao_h265_device_planes(hevcdbk_context *ctx, const hevcdbk_devi
         can[i] = dbk_packed_h265_supports(h[i], (int)planes[i].sample_bytes, i != 0) &&
                  dbk_deblock_sao_supports(h[i].base, sa[i], (int)planes[i].sample_bytes, i != 0);
         one = one && (i == 0 || planes[i].is_chroma) && planes[i].sample_bytes == planes[0].sample_bytes &&
-              planes[i].bit_depth == planes[0].bit_depth && can[i];
+              planes[i].bit_depth == planes[0].bit_depth && (h[i].base.qp_map != nullptr) == (h[0].base.qp_map != nullptr) && can[i];
     }
     if (int rc = bind(ctx)) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->compute;

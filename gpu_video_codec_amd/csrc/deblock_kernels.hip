@@ -1241,7 +1241,7 @@ hipError_t dbk_launch_packed_h265(const DbkH265Args &h, int sample_bytes, bool c
 /* ---- deblocking + SAO in one kernel ---- */
 bool dbk_deblock_sao_supports(const DbkArgs &d, const DbkSaoArgs &s, int sample_bytes, bool chroma)
 {
-    if (d.qp_map || d.by_count != 0 || d.max_v != s.max_v) return false;
+    if (d.by_count != 0 || d.max_v != s.max_v) return false;
     if (sample_bytes == 1) {
         if (d.max_v != 255 || s.band_shift != 3) return false;
     } else {
@@ -1290,20 +1290,28 @@ static void fused_h265_scalars(DbkH265Args &d, bool chroma)
     }
 }
 
+/* launch K<..., QPMAP> with QPMAP = the plane carries a QP map */
+#define DBK_FUSED_LAUNCH(qm, K, threads, lds, ...)                                                 \
+    do {                                                                                           \
+        if (qm) DBK_LAUNCH_LDS((K<__VA_ARGS__, true>), grid, dim3(threads), lds, stream, fa);      \
+        else DBK_LAUNCH_LDS((K<__VA_ARGS__, false>), grid, dim3(threads), lds, stream, fa);        \
+    } while (0)
+
 hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, int sample_bytes, bool chroma, hipStream_t stream)
 {
     if (d.n_frames <= 0 || d.nbx <= 0 || d.nby <= 0) return hipSuccess;
     DbkFusedArgs fa;
     fa.d = d;
     fa.s = s;
+    const bool qm = d.qp_map != nullptr;
     const dim3 grid(fused_grid(d.plane_w, d.plane_h, d.n_frames, sample_bytes, fa.g), 1, 1);
     if (sample_bytes == 1) {
-        if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused_kernel<true>), grid, dim3(kFusedThreads), kFusedLds, stream, fa);
-        else DBK_LAUNCH_LDS((dbk_sao_fused_kernel<false>), grid, dim3(kFusedThreads), kFusedLds, stream, fa);
+        if (chroma) DBK_FUSED_LAUNCH(qm, dbk_sao_fused_kernel, kFusedThreads, kFusedLds, true);
+        else DBK_FUSED_LAUNCH(qm, dbk_sao_fused_kernel, kFusedThreads, kFusedLds, false);
     } else {
-        if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused16_kernel<true, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
-        else if (d.max_v > 2047) DBK_LAUNCH_LDS((dbk_sao_fused16_kernel<false, true>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
-        else DBK_LAUNCH_LDS((dbk_sao_fused16_kernel<false, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
+        if (chroma) DBK_FUSED_LAUNCH(qm, dbk_sao_fused16_kernel, kFused16Threads, kFused16Lds, true, false);
+        else if (d.max_v > 2047) DBK_FUSED_LAUNCH(qm, dbk_sao_fused16_kernel, kFused16Threads, kFused16Lds, false, true);
+        else DBK_FUSED_LAUNCH(qm, dbk_sao_fused16_kernel, kFused16Threads, kFused16Lds, false, false);
     }
     return hipGetLastError();
 }
@@ -1315,14 +1323,15 @@ hipError_t dbk_launch_deblock_sao_h265(const DbkH265Args &h, const DbkSaoArgs &s
     fa.d = h;
     fa.s = s;
     fused_h265_scalars(fa.d, chroma);
+    const bool qm = h.base.qp_map != nullptr;
     const dim3 grid(fused_grid(h.base.plane_w, h.base.plane_h, h.base.n_frames, sample_bytes, fa.g), 1, 1);
     if (sample_bytes == 1) {
-        if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused_h265_kernel<true>), grid, dim3(kFusedThreads), kFusedLds, stream, fa);
-        else DBK_LAUNCH_LDS((dbk_sao_fused_h265_kernel<false>), grid, dim3(kFusedThreads), kFusedLds, stream, fa);
+        if (chroma) DBK_FUSED_LAUNCH(qm, dbk_sao_fused_h265_kernel, kFusedThreads, kFusedLds, true);
+        else DBK_FUSED_LAUNCH(qm, dbk_sao_fused_h265_kernel, kFusedThreads, kFusedLds, false);
     } else {
-        if (chroma) DBK_LAUNCH_LDS((dbk_sao_fused16_h265_kernel<true, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
-        else if (h.base.max_v > 2047) DBK_LAUNCH_LDS((dbk_sao_fused16_h265_kernel<false, true>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
-        else DBK_LAUNCH_LDS((dbk_sao_fused16_h265_kernel<false, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, fa);
+        if (chroma) DBK_FUSED_LAUNCH(qm, dbk_sao_fused16_h265_kernel, kFused16Threads, kFused16Lds, true, false);
+        else if (h.base.max_v > 2047) DBK_FUSED_LAUNCH(qm, dbk_sao_fused16_h265_kernel, kFused16Threads, kFused16Lds, false, true);
+        else DBK_FUSED_LAUNCH(qm, dbk_sao_fused16_h265_kernel, kFused16Threads, kFused16Lds, false, false);
     }
     return hipGetLastError();
 }
@@ -1343,9 +1352,11 @@ hipError_t dbk_launch_deblock_sao_multi(const DbkArgs *d, const DbkSaoArgs *s, i
         m.wg_end[i] = total;
     }
     const dim3 grid(total, 1, 1);
-    if (sample_bytes == 1) DBK_LAUNCH_LDS((dbk_sao_fused_multi_kernel<1, false>), grid, dim3(kFusedThreads), kFusedLds, stream, m);
-    else if (d[0].max_v > 2047) DBK_LAUNCH_LDS((dbk_sao_fused_multi_kernel<2, true>), grid, dim3(kFused16Threads), kFused16Lds, stream, m);
-    else DBK_LAUNCH_LDS((dbk_sao_fused_multi_kernel<2, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, m);
+    const DbkFusedMultiArgs &fa = m;
+    const bool qm = d[0].qp_map != nullptr; /* the caller checked: all planes with a map, or none */
+    if (sample_bytes == 1) DBK_FUSED_LAUNCH(qm, dbk_sao_fused_multi_kernel, kFusedThreads, kFusedLds, 1, false);
+    else if (d[0].max_v > 2047) DBK_FUSED_LAUNCH(qm, dbk_sao_fused_multi_kernel, kFused16Threads, kFused16Lds, 2, true);
+    else DBK_FUSED_LAUNCH(qm, dbk_sao_fused_multi_kernel, kFused16Threads, kFused16Lds, 2, false);
     return hipGetLastError();
 }
 
@@ -1366,8 +1377,10 @@ hipError_t dbk_launch_deblock_sao_multi_h265(const DbkH265Args *h, const DbkSaoA
         m.wg_end[i] = total;
     }
     const dim3 grid(total, 1, 1);
-    if (sample_bytes == 1) DBK_LAUNCH_LDS((dbk_sao_fused_multi_h265_kernel<1, false>), grid, dim3(kFusedThreads), kFusedLds, stream, m);
-    else if (h[0].base.max_v > 2047) DBK_LAUNCH_LDS((dbk_sao_fused_multi_h265_kernel<2, true>), grid, dim3(kFused16Threads), kFused16Lds, stream, m);
-    else DBK_LAUNCH_LDS((dbk_sao_fused_multi_h265_kernel<2, false>), grid, dim3(kFused16Threads), kFused16Lds, stream, m);
+    const DbkFusedMultiH265Args &fa = m;
+    const bool qm = h[0].base.qp_map != nullptr; /* the caller checked: all planes with a map, or none */
+    if (sample_bytes == 1) DBK_FUSED_LAUNCH(qm, dbk_sao_fused_multi_h265_kernel, kFusedThreads, kFusedLds, 1, false);
+    else if (h[0].base.max_v > 2047) DBK_FUSED_LAUNCH(qm, dbk_sao_fused_multi_h265_kernel, kFused16Threads, kFused16Lds, 2, true);
+    else DBK_FUSED_LAUNCH(qm, dbk_sao_fused_multi_h265_kernel, kFused16Threads, kFused16Lds, 2, false);
     return hipGetLastError();
 }

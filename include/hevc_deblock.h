@@ -398,10 +398,10 @@ HEVCDBK_API int hevc_sao_filter_device(hevcdbk_context *ctx, const hevcdbk_devic
  * a decoder.  Operands as for hevc_deblocking_filter_device (reference-exact mode: `qp`, `tables`, the
  * planes' bS arrays) resp. hevc_deblocking_filter_h265_device (spec-exact mode: `c_idx`, `qp`, `h265_params`, the planes'
  * 4-sample-granular bS arrays) and for hevc_sao_filter_device (`params` ... `keep_frame_stride`, all DEVICE memory).
- * For 8-bit planes and for 16-bit containers up to 12 bit, with a scalar QP, both stages run in ONE kernel: a workgroup
+ * For 8-bit planes and for 16-bit containers up to 12 bit, with one QP or a QP map, both stages run in ONE kernel: a workgroup
  * deblocks the offset blocks of a tile (8 bit: 192 x 128 samples, 16-bit containers: 128 x 128; plus a one-sample rim) into
  * LDS and applies SAO from there, so every sample is read from HBM once and written once and the deblocked picture never
- * exists in memory.  Other operands (QP maps, samples deeper than 12 bit) run as two launches through a scratch plane owned
+ * exists in memory.  Other operands (samples deeper than 12 bit, misaligned 16-bit planes) run as two launches through a scratch plane owned
  * by the context.  `fused`: HEVCDBK_FUSED_AUTO picks, _OFF forces the two launches (same bytes; for A/B runs), _ON returns
  * HEVCDBK_ERR_UNSUPPORTED where the fused kernel does not apply.  The scratch plane of the two-launch form belongs to the
  * context and is reused by the next such call; its reuse is fenced by an event, so calls that hand in different streams are

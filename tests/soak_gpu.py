@@ -95,8 +95,8 @@ def main():
                 if b.qp_map is not None:
                     b.qp_map.free()
                 b.free()
-        # scalar-QP cases up to 12 bit also through deblocking + SAO in one kernel (and as two launches), both filter modes
-        if bd <= 12 and not use_map and not in_place:
+        # cases up to 12 bit (one QP or the QP map) also through deblocking + SAO in one kernel (and as two launches), both filter modes
+        if bd <= 12 and not in_place:
             ctb_log2 = int(rng.choice([3, 4, 5, 6]))
             prm = np.stack([h265.random_sao_params(w, h, ctb_log2, seed=int(rng.randint(1, 1 << 30)), bit_depth=bd) for _ in range(n)])
             keep = (rng.randint(0, 5, (n, h // 8, w // 8)) == 0).astype(np.uint8)
@@ -107,9 +107,11 @@ def main():
             b = deblock.DeviceBatch(ctx, w, h, n, bit_depth=bd, is_chroma=chroma, per_frame_bs=False)
             b.upload_all(frames)
             b.set_bs(0, rvb, rhb)
+            if qmap is not None:
+                b.set_qp_map(qmap, 6)
             want = [h265.sao_plane(want_ref[f], prm[f], ctb_log2, bit_depth=bd, keep=keep[f]) for f in range(n)]
             for fused in (_lib.FUSED_ON, _lib.FUSED_OFF):
-                ctx.deblock_sao_device(b.planes(), qp, dp.ptr, prm.shape[2], ctb_log2, fused=fused, **kw)
+                ctx.deblock_sao_device(b.planes(), 0 if use_map else qp, dp.ptr, prm.shape[2], ctb_log2, fused=fused, **kw)
                 ctx.synchronize()
                 for f in range(n):
                     if not np.array_equal(b.download_frame(f), want[f]):
@@ -120,6 +122,11 @@ def main():
             dh.upload(hb)
             p = b.planes()
             p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
+            dm2 = None
+            if smap is not None:
+                dm2 = ctx.alloc(smap.nbytes)
+                dm2.upload(smap)
+                p.qp_map, p.qp_map_stride, p.ctu_log2, p.qp_map_frame_stride = dm2.ptr, smap.shape[1], 3, 0
             want = [h265.sao_plane(want_spec[f], prm[f], ctb_log2, bit_depth=bd, keep=keep[f]) for f in range(n)]
             for fused in (_lib.FUSED_ON, _lib.FUSED_OFF):
                 ctx.deblock_sao_h265_device(p, qp_s, dp.ptr, prm.shape[2], ctb_log2, c_idx=1 if chroma else 0, cb_qp_offset=cq, fused=fused, **offs, **kw)
@@ -128,7 +135,7 @@ def main():
                     if not np.array_equal(b.download_frame(f), want[f]):
                         print("MISMATCH deblock+sao spec", fused, f, tag, ctb_log2, offs, cq)
                         bad += 1
-            for x in (dp, dk, dv, dh):
+            for x in (dp, dk, dv, dh) + ((dm2,) if dm2 is not None else ()) + ((b.qp_map,) if b.qp_map is not None else ()):
                 x.free()
             b.free()
         # every third case also as a whole 4:2:0 frame batch: Y, U, V in one call (the fused launch where it applies, 8-bit and

@@ -422,6 +422,103 @@ def test_deblock_sao_yuv420_one_launch(ctx, h265, oracle):
         x.free()
 
 
+def test_deblock_sao_with_qp_map(ctx, h265, oracle):
+    """The fused deblocking + SAO kernels with a QP map (QP per unit of 8 .. 64 luma samples, as a decoder with cu_qp_delta
+    has it) instead of one QP: single planes (luma and chroma, 8 / 10 / 12 bit, both filter modes) and the three planes of a
+    4:2:0 batch in one launch, FUSED_ON / AUTO / OFF, against SAO(deblock(x)) of the oracles with the same map."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    rng = np.random.RandomState(41)
+    for (w, h, bd, chroma, unit_log2, ctb_log2) in ((392, 264, 8, False, 3, 6), (200, 136, 8, True, 4, 5), (264, 136, 10, False, 4, 5),
+                                                    (136, 392, 12, False, 6, 6), (136, 72, 10, True, 3, 4), (3840, 136, 8, False, 5, 6)):
+        n = 2
+        sc = 2 if chroma else 1
+        fr = np.stack([synth.blocky_plane(w, h, seed=w + i, bit_depth=bd) for i in range(n)])
+        fr = np.clip(fr.astype(np.int32) + rng.randint(-3, 4, fr.shape), 0, (1 << bd) - 1).astype(fr.dtype)
+        qmap = synth.ctu_qp_map(w * sc, h * sc, seed=bd + w, lo=20, hi=51, ctu_log2=unit_log2)
+        prm = h265.random_sao_params(w, h, ctb_log2, seed=w, bit_depth=bd)
+        dp = ctx.alloc(prm.nbytes)
+        dp.upload(prm.view(np.uint8).ravel())
+        b = deblock.DeviceBatch(ctx, w, h, n, bit_depth=bd, is_chroma=chroma, per_frame_bs=False)
+        b.upload_all(fr)
+        b.set_qp_map(qmap, unit_log2)
+        want = [h265.sao_plane(oracle.filter_plane(fr[f], 0, is_chroma=chroma, bit_depth=bd, qp_map=qmap, ctu_log2=unit_log2), prm, ctb_log2,
+                               bit_depth=bd) for f in range(n)]
+        for fused in (_lib.FUSED_ON, _lib.FUSED_AUTO, _lib.FUSED_OFF):
+            b.dst.upload(np.zeros(b.frame_bytes * n, np.uint8))
+            ctx.deblock_sao_device(b.planes(), 0, dp.ptr, prm.shape[1], ctb_log2, fused=fused)
+            ctx.synchronize()
+            for f in range(n):
+                assert np.array_equal(b.download_frame(f), want[f]), ("ref", w, h, bd, chroma, fused, f)
+        vb, hb = rand_bs(h265, w, h, rng)
+        dv, dh = ctx.alloc(vb.size), ctx.alloc(hb.size)
+        dv.upload(vb)
+        dh.upload(hb)
+        p = b.planes()
+        p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
+        c_idx, cq = (2, -3) if chroma else (0, 0)
+        want = [h265.sao_plane(h265.filter_plane(fr[f], 0, vb, hb, c_idx=c_idx, bit_depth=bd, qp_map=qmap, unit_log2=unit_log2, c_qp_offset=cq,
+                                                 tc_offset_div2=1, beta_offset_div2=-2), prm, ctb_log2, bit_depth=bd) for f in range(n)]
+        for fused in (_lib.FUSED_ON, _lib.FUSED_AUTO, _lib.FUSED_OFF):
+            b.dst.upload(np.zeros(b.frame_bytes * n, np.uint8))
+            ctx.deblock_sao_h265_device(p, 0, dp.ptr, prm.shape[1], ctb_log2, c_idx=c_idx, cr_qp_offset=cq, tc_offset_div2=1, beta_offset_div2=-2,
+                                        fused=fused)
+            ctx.synchronize()
+            for f in range(n):
+                assert np.array_equal(b.download_frame(f), want[f]), ("spec", w, h, bd, chroma, fused, f)
+        b.qp_map.free()
+        for x in (dp, dv, dh):
+            x.free()
+        b.free()
+    # Y + U + V in one launch, every plane reading the (luma-unit) map
+    for (w, h, bd, unit_log2) in ((400, 272, 8, 3), (272, 144, 10, 4)):
+        n = 2
+        qmap = synth.ctu_qp_map(w, h, seed=w, lo=22, hi=48, ctu_log2=unit_log2)
+        dims = [(w, h, 6), (w // 2, h // 2, 5), (w // 2, h // 2, 5)]
+        bats, sao, dev, wr, ws, sp = [], [], [], [], [], []
+        for i, (pw, ph, cl) in enumerate(dims):
+            fr = np.stack([synth.blocky_plane(pw, ph, seed=5 * i + f + w, bit_depth=bd) for f in range(n)])
+            b = deblock.DeviceBatch(ctx, pw, ph, n, bit_depth=bd, is_chroma=i > 0, per_frame_bs=False)
+            b.upload_all(fr)
+            b.set_qp_map(qmap, unit_log2)
+            prm = h265.random_sao_params(pw, ph, cl, seed=i + w, bit_depth=bd)
+            dp = ctx.alloc(prm.nbytes)
+            dp.upload(prm.view(np.uint8).ravel())
+            vb, hb = rand_bs(h265, pw, ph, rng)
+            dv, dh = ctx.alloc(vb.size), ctx.alloc(hb.size)
+            dv.upload(vb)
+            dh.upload(hb)
+            dev += [dp, dv, dh]
+            bats.append(b)
+            sao.append((dp.ptr, prm.shape[1], cl))
+            wr.append([h265.sao_plane(oracle.filter_plane(fr[f], 0, is_chroma=i > 0, bit_depth=bd, qp_map=qmap, ctu_log2=unit_log2), prm, cl,
+                                      bit_depth=bd) for f in range(n)])
+            ws.append([h265.sao_plane(h265.filter_plane(fr[f], 0, vb, hb, c_idx=i, bit_depth=bd, qp_map=qmap, unit_log2=unit_log2,
+                                                        c_qp_offset=(0, 1, -2)[i]), prm, cl, bit_depth=bd) for f in range(n)])
+            p = b.planes()
+            p.vert_bs, p.hor_bs, p.vert_bs_stride, p.hor_bs_stride = dv.ptr, dh.ptr, 0, 0
+            sp.append(p)
+        for fused in (_lib.FUSED_ON, _lib.FUSED_OFF):
+            for b in bats:
+                b.dst.upload(np.zeros(b.frame_bytes * n, np.uint8))
+            ctx.deblock_sao_device_planes([b.planes() for b in bats], 0, sao, fused=fused)
+            ctx.synchronize()
+            for i, b in enumerate(bats):
+                for f in range(n):
+                    assert np.array_equal(b.download_frame(f), wr[i][f]), ("ref planes", w, bd, fused, i, f)
+            for b in bats:
+                b.dst.upload(np.zeros(b.frame_bytes * n, np.uint8))
+            ctx.deblock_sao_device_planes(sp, 0, sao, h265=dict(cb_qp_offset=1, cr_qp_offset=-2), fused=fused)
+            ctx.synchronize()
+            for i, b in enumerate(bats):
+                for f in range(n):
+                    assert np.array_equal(b.download_frame(f), ws[i][f]), ("spec planes", w, bd, fused, i, f)
+        for b in bats:
+            b.qp_map.free()
+            b.free()
+        for d in dev:
+            d.free()
+
+
 def test_random_geometry_sweep_both_modes(ctx, h265, oracle):
     """Seeded sweep over plane geometries (widths around the wave / workgroup boundaries included), both filter modes,
     both kernels, 8 and 10 bit, luma and chroma, in place and src -> dst: any indexing slip at a frame edge, a partial wave
