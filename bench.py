@@ -533,8 +533,32 @@ def extra_h265_stages(ctx, args, frames, batch, steps, wall_settled):
                            "ms_per_step": dt * 1e3, "frac": nbytes / dt / (HBM_PEAK_GBPS * 1e9), "achieved_GBps": nbytes / dt * 1e-9,
                            "algorithmic_bytes": nbytes, "steps": 4 * steps, "settle_ms": info["settle_ms"], "bit_exact_vs_oracle": ok,
                            "parity": "unpinned: checked against this repository's own restatement of H.265 8.7.2"}
-    dv.free()
-    dh.free()
+    # the in-loop chain as a decoder has it: spec-exact deblocking with a QP per 16x16 quantization group (cu_qp_delta) + SAO,
+    # ONE kernel, against the two launches
+    from gpu_video_codec_amd import synth
+    qmap = synth.ctu_qp_map(w, h, seed=29, lo=max(qp - 6, 0), hi=min(qp + 6, 51), ctu_log2=4)
+    dm = ctx.alloc(qmap.nbytes)
+    dm.upload(qmap)
+    ph.qp_map, ph.qp_map_stride, ph.ctu_log2, ph.qp_map_frame_stride = dm.ptr, qmap.shape[1], 4, 0
+    prm = h265.random_sao_params(w, h, 6, seed=31, bit_depth=bd)
+    dp = ctx.alloc(prm.nbytes)
+    dp.upload(prm.view(np.uint8).ravel())
+    want = h265.sao_plane(h265.filter_plane(frames[Fs - 1], 0, vb, hb, qp_map=qmap, unit_log2=4), prm, 6)
+    r = {}
+    for name, fused in (("one_kernel", _lib.FUSED_ON), ("two_launches", _lib.FUSED_OFF)):
+        r[name], r[name + "_info"] = wall_settled(lambda: ctx.deblock_sao_h265_device(ph, 0, dp.ptr, prm.shape[1], 6, fused=fused), steps)
+        r[name + "_ok"] = bool(np.array_equal(batch.download_frame(Fs - 1), want))
+    nbytes = Fs * (2 * w * h + vb.size + hb.size + qmap.size)
+    out["h265_deblock_sao_qpmap_64"] = {
+        "workload": "spec-exact deblocking (QP per 16x16 group, %d..%d, bS 2 on every interior edge) + SAO of %dx%d 8-bit luma in ONE "
+                    "kernel, %d frames per call, src -> dst, wall clock per call" % (int(qmap.min()), int(qmap.max()), w, h, Fs),
+        "ms_per_step": r["one_kernel"] * 1e3, "ms_per_step_two_launches": r["two_launches"] * 1e3,
+        "speedup_over_two_launches": r["two_launches"] / r["one_kernel"], "frac": nbytes / r["one_kernel"] / (HBM_PEAK_GBPS * 1e9),
+        "algorithmic_bytes": nbytes, "steps": steps, "settle_ms": r["one_kernel_info"]["settle_ms"],
+        "bit_exact_vs_oracle": r["one_kernel_ok"] and r["two_launches_ok"],
+        "parity": "unpinned: checked against this repository's own restatements of H.265 8.7.2 / 8.7.3"}
+    for d in (dm, dp, dv, dh):
+        d.free()
     return out
 
 

@@ -101,7 +101,8 @@ DBK_HD H265Uni h265_uni(int beta, int tc_bs1, int tc_bs2)
  * carries a keep flag (PCM / transquant bypass are rare, and a picture's edges are mostly intra = 2 or mostly inter = 1):
  * such a wave runs the SAME code as the reference-exact kernel -- decisions through saturating subtractions and biased
  * adds, the three-instruction strong clamp, one conservative |delta| test, operands in SGPRs -- with the standard's
- * thresholds and clip (LumaKLazy<true>).  A wave with mixed bS or a keep flag takes the general per-lane form below.
+ * thresholds and clip (LumaKLazy<true>).  A wave with both bS values runs that core with per-lane operands (LumaKEager); only
+ * a wave with a keep flag takes the general per-lane form below.
  */
 template <bool WIDE = false>
 DBK_HD void luma_pairs_h265(Taps &a, Taps &b, int entry, int beta, int tc, int max_v);
@@ -114,6 +115,25 @@ DBK_HD void luma_pairs_h265_uni(Taps &a, Taps &b, int entry, int beta, int tc, i
     if (mk == 0ull && (m1 == 0ull || m2 == 0ull)) {
         /* the wave's one tc is picked on the scalar unit and the segment constants are built from it right here */
         if (bs != 0) luma_pairs<WIDE, true>(a, b, LumaKLazy<true>{u.beta, m2 != 0ull ? u.tc2 : u.tc1}, max_v);
+    } else if (mk == 0ull) {
+        /* bS 1 and bS 2 side by side (inter pictures): the same core with per-lane operands, as the QP-map kernels run it */
+        if (bs != 0) luma_pairs<WIDE, false>(a, b, LumaKEager::make<true>(beta, tc), max_v);
+    } else {
+        luma_pairs_h265<WIDE>(a, b, entry, beta, tc, max_v);
+    }
+}
+
+/*
+ * One luma segment, QP-map kernels: beta and tc differ from lane to lane anyway (tc already carries the lane's bS), so a
+ * mix of bS values costs nothing; a wave in which no filtering lane carries a keep flag runs the shared core with per-lane
+ * operands (LumaKEager, the standard's thresholds), any other wave the general form.
+ */
+template <bool WIDE = false>
+DBK_HD void luma_pairs_h265_map(Taps &a, Taps &b, int entry, int beta, int tc, int max_v)
+{
+    const int bs = entry & kH265BsMask;
+    if (lane_ballot(bs != 0 && (entry & (kH265KeepP | kH265KeepQ)) != 0) == 0ull) {
+        if (bs != 0) luma_pairs<WIDE, false>(a, b, LumaKEager::make<true>(beta, tc), max_v);
     } else {
         luma_pairs_h265<WIDE>(a, b, entry, beta, tc, max_v);
     }
@@ -159,7 +179,7 @@ template <bool WIDE = false>
 DBK_HD void luma_seg_h265(Taps &a, Taps &b, const H265Seg &s, int i, int max_v, const H265Uni *u)
 {
     if (u) luma_pairs_h265_uni<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v, *u);
-    else luma_pairs_h265<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v);
+    else luma_pairs_h265_map<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v);
 }
 
 /* 8-bit luma block: ver1 -> ver2 -> hor1 -> hor2 with the conformant hor2 (P and Q both in columns 4..7) */
