@@ -193,4 +193,26 @@ DBK_HD int seg_qp_from_map(const uint8_t *map, int map_stride, int ctu_log2, int
     return q > 51 ? 51 : q;
 }
 
+/*
+ * The same QPs with half the look-ups, for the packed kernels: an offset block lies across the corner where four 8x8-aligned
+ * blocks meet, a map unit is at least 8x8 luma samples, so the eight positions the four segments ask for fall into FOUR map
+ * units -- above-left, above-right, below-left, below-right of the block's centre -- whatever the unit size and the plane
+ * (chroma positions are doubled first; out-of-picture positions clamp into the picture exactly as above).
+ * q = {TL, TR, BL, BR}.  Requires unit_log2 >= 3 (checked by the entry points).
+ */
+DBK_HD void block_unit_qps(const uint8_t *map, int map_stride, int unit_log2, int sc, int lw, int lh, int x0, int y0, int (&q)[4])
+{
+    const int xl = clampi((x0 + 3) * sc, 0, lw - 1) >> unit_log2, xr = clampi((x0 + 4) * sc, 0, lw - 1) >> unit_log2;
+    const int yt = clampi((y0 + 3) * sc, 0, lh - 1) >> unit_log2, yb = clampi((y0 + 4) * sc, 0, lh - 1) >> unit_log2;
+    q[0] = map[yt * map_stride + xl];
+    q[1] = map[yt * map_stride + xr];
+    q[2] = map[yb * map_stride + xl];
+    q[3] = map[yb * map_stride + xr];
+}
+DBK_HD int seg_qp_avg(int qp_p, int qp_q)
+{
+    const int q = (qp_p + qp_q + 1) >> 1;
+    return q > 51 ? 51 : q;
+}
+
 } /* namespace dbk */

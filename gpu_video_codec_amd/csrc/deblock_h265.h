@@ -196,6 +196,16 @@ DBK_HD void h265_block_qpl(const uint8_t *map, int map_stride, int unit_log2, in
     qpl[2] = seg_qp_from_map(map, map_stride, unit_log2, sc, lw, lh, x0 + 0, y0 + 3, x0 + 0, y0 + 4);
     qpl[3] = seg_qp_from_map(map, map_stride, unit_log2, sc, lw, lh, x0 + 4, y0 + 3, x0 + 4, y0 + 4);
 }
+/* the packed kernels' form: four map look-ups instead of eight (block_unit_qps, deblock_core.h); same values */
+DBK_HD void h265_block_qpl4(const uint8_t *map, int map_stride, int unit_log2, int sc, int lw, int lh, int x0, int y0, int (&qpl)[4])
+{
+    int q[4];
+    block_unit_qps(map, map_stride, unit_log2, sc, lw, lh, x0, y0, q);
+    qpl[0] = seg_qp_avg(q[0], q[1]); /* ver1: above-left | above-right */
+    qpl[1] = seg_qp_avg(q[2], q[3]); /* ver2: below-left | below-right */
+    qpl[2] = seg_qp_avg(q[0], q[2]); /* hor1: above-left / below-left */
+    qpl[3] = seg_qp_avg(q[1], q[3]); /* hor2: above-right / below-right */
+}
 
 /* ---- bS derivation, 8.7.2.4, on per-4x4-unit prediction data -------------------------------------------- */
 

@@ -264,10 +264,12 @@ __device__ __forceinline__ dbk::BlockQp block_qp(const DbkArgs &a, int f, int by
         const uint8_t *map = a.qp_map + (long long)f * a.map_frame_stride;
         const int sc = CHROMA ? 2 : 1, lw = a.plane_w * sc, lh = a.plane_h * sc;
         const int x0 = bx * 8 - 4, y0 = by * 8 - 4;
-        const int qp0 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 3, y0 + 0, x0 + 4, y0 + 0);
-        const int qp1 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 3, y0 + 4, x0 + 4, y0 + 4);
-        const int qp2 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 0, y0 + 3, x0 + 0, y0 + 4);
-        const int qp3 = dbk::seg_qp_from_map(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0 + 4, y0 + 3, x0 + 0, y0 + 4);
+        /* the generic kernel's eight look-ups (seg_qp_from_map per segment) are four map units: above-left, above-right,
+         * below-left, below-right of the block's centre (block_unit_qps); hor2 pairs above-right with below-LEFT (cpu.h:383-414) */
+        int u[4];
+        dbk::block_unit_qps(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0, y0, u);
+        const int qp0 = dbk::seg_qp_avg(u[0], u[1]), qp1 = dbk::seg_qp_avg(u[2], u[3]);
+        const int qp2 = dbk::seg_qp_avg(u[0], u[2]), qp3 = dbk::seg_qp_avg(u[1], u[2]);
         q.tc[0] = a.tc_tab[qp0] << a.shift; q.beta[0] = a.beta_tab[qp0] << a.shift;
         q.tc[1] = a.tc_tab[qp1] << a.shift; q.beta[1] = a.beta_tab[qp1] << a.shift;
         q.tc[2] = a.tc_tab[qp2] << a.shift; q.beta[2] = a.beta_tab[qp2] << a.shift;
@@ -448,8 +450,8 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         if constexpr (QPMAP) {
             int qpl[4];
             const int sc = CHROMA ? 2 : 1, bxa = active ? bx : 0;
-            dbk::h265_block_qpl(a.qp_map + (long long)f * a.map_frame_stride, a.map_stride, a.ctu_log2, sc, a.plane_w * sc,
-                                a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, hx->qp, qpl);
+            dbk::h265_block_qpl4(a.qp_map + (long long)f * a.map_frame_stride, a.map_stride, a.ctu_log2, sc, a.plane_w * sc,
+                                 a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, qpl);
             const dbk::H265Prm prm = {hx->tc_off, hx->beta_off, hx->c_qp_offset, 0, 255};
             dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);
         } else { /* one QP: beta is a scalar and tc one of two scalars picked by the bS */
@@ -594,8 +596,8 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
         if constexpr (QPMAP) {
             int qpl[4];
             const int sc = CHROMA ? 2 : 1, bxa = active ? bx : 0;
-            dbk::h265_block_qpl(a.qp_map + (long long)f * a.map_frame_stride, a.map_stride, a.ctu_log2, sc, a.plane_w * sc,
-                                a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, hx->qp, qpl);
+            dbk::h265_block_qpl4(a.qp_map + (long long)f * a.map_frame_stride, a.map_stride, a.ctu_log2, sc, a.plane_w * sc,
+                                 a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, qpl);
             const dbk::H265Prm prm = {hx->tc_off, hx->beta_off, hx->c_qp_offset, a.shift, a.max_v};
             dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);
         } else {
