@@ -486,6 +486,37 @@ def extra_deblock_sao(ctx, args, frames, batch, cb, steps, wall_settled):
         "frac": nb10 / r10["one_kernel"] / (HBM_PEAK_GBPS * 1e9), "algorithmic_bytes": nb10, "steps": steps,
         "settle_ms": r10["one_kernel_info"]["settle_ms"], "bit_exact_vs_oracle": r10["one_kernel_ok"] and r10["two_launches_ok"],
         "parity": "unpinned beyond 8 bit and for the SAO stage: checked against this repository's own restatements"}
+    # ---- ... and whole 10-bit 4:2:0 frames (Main 10: what a 4K HEVC decoder mostly sees), Y + U + V in ONE launch
+    cw, ch = w // 2, h // 2
+    c10, dev10, sao10, okc = [], [], [(d10.ptr, prm10.shape[1], 6)], True
+    for i in range(2):
+        fc = make_frames(cw, ch, 4, bd2, seed=13 + i, n_base=2)
+        bc = deblock.DeviceBatch(ctx, cw, ch, Fs, bit_depth=bd2, is_chroma=True, per_frame_bs=False)
+        bc.upload_all(np.concatenate([fc] * (Fs // 4 + 1))[:Fs])
+        pc = h265.random_sao_params(cw, ch, 5, seed=37 + i, bit_depth=bd2)
+        dc = ctx.alloc(pc.nbytes)
+        dc.upload(pc.view(np.uint8).ravel())
+        c10.append((bc, fc, pc))
+        dev10.append(dc)
+        sao10.append((dc.ptr, pc.shape[1], 5))
+    pl10 = [p10] + [bc.planes() for bc, _f, _p in c10]
+    t10, i10 = wall_settled(lambda: ctx.deblock_sao_device_planes(pl10, qp, sao10, fused=_lib.FUSED_ON), steps)
+    okc &= bool(np.array_equal(b10.download_frame(Fs - 1), h265.sao_plane(oracle.filter_plane(f10[(Fs - 1) % 8], qp, bit_depth=bd2, threads=8),
+                                                                           prm10, 6, bit_depth=bd2)))
+    for bc, fc, pc in c10:
+        okc &= bool(np.array_equal(bc.download_frame(1), h265.sao_plane(oracle.filter_plane(fc[1], qp, is_chroma=True, bit_depth=bd2), pc, 5,
+                                                                         bit_depth=bd2)))
+    nb = 2 * Fs * (w * h + 2 * cw * ch) * 2
+    out["deblock_sao_fused_yuv420_10bit"] = {
+        "workload": "%dx%d 10-bit 4:2:0 (Y+U+V, 16-bit containers), %d frames per call, deblocking + SAO of the three planes in ONE launch, "
+                    "src -> dst, wall clock per call" % (w, h, Fs),
+        "ms_per_step": t10 * 1e3, "yuv420_frames_per_s": Fs / t10, "frac": nb / t10 / (HBM_PEAK_GBPS * 1e9), "algorithmic_bytes": nb,
+        "steps": steps, "settle_ms": i10["settle_ms"], "bit_exact_vs_oracle": okc,
+        "parity": "unpinned beyond 8 bit and for the SAO stage: checked against this repository's own restatements"}
+    for bc, _f, _p in c10:
+        bc.free()
+    for d in dev10:
+        d.free()
     d10.free()
     b10.free()
     return out

@@ -84,18 +84,18 @@ __device__ __forceinline__ uint32_t band_sel(uint32_t rec, int shift, spk pos)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(s_upk(k), s_upk(kSel | 0x00040004u)));
 }
 
-/* the 8 output rows of an edge-offset block from its ten raw rows, class CLS of Table 8-13: 0 (-1,0)/(1,0); 1 (0,-1)/(0,1);
+/* the NROWS (8) output rows of an edge-offset block from its NROWS + 2 (ten) raw rows, class CLS of Table 8-13: 0 (-1,0)/(1,0); 1 (0,-1)/(0,1);
  * 2 (-1,-1)/(1,1); 3 (1,-1)/(-1,1).  BORDER: the block may touch the picture border (x, y0 = its position, w x h the picture):
  * a sample with a neighbour outside the picture gets no offset (8.7.3.2), whatever the raw rows hold there.
  * store(r, lo, hi) takes output row r as its two dwords. */
-template <int CLS, bool BORDER, typename Fetch, typename Store>
+template <int CLS, bool BORDER, int NROWS, typename Fetch, typename Store>
 __device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store, int x, int y0, int w, int h, uint32_t tab_lo,
                                           uint32_t tab_hi)
 {
     constexpr bool horizontal = CLS != 1, vertical = CLS != 0;
     SaoRow up = unpack<horizontal>(fetch(0)), mid = unpack<horizontal>(fetch(1)), dn;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
+    for (int r = 0; r < NROWS; r++) {
         const int y = y0 + r;
         dn = unpack<horizontal>(fetch(r + 2));
         uint32_t i0, i1, i2, i3; /* indices of E0, O0, E1, O1 */
@@ -133,14 +133,18 @@ __device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store
     }
 }
 
-/* one 8x8 block: not applied / kept (copy), band offset, or edge offset.  fetch(i) returns raw row i = image row y0 - 1 + i
- * (i = 0 .. 9; rows 0 and 9 are asked for by the edge classes only) -- from registers, or from LDS as the rows are needed */
-template <bool BORDER, typename Fetch, typename Store>
+/* one block of 8 x NROWS samples inside one CTB: not applied / kept (copy), band offset, or edge offset.  fetch(i) returns raw
+ * row i = image row y0 - 1 + i (i = 0 .. NROWS + 1; the first and last are asked for by the edge classes only) -- from registers,
+ * or from LDS as the rows are needed.  NROWS = 8: a lane's block is the keep map's unit and a wave (64 lanes) covers 64 x 64
+ * samples -- one CTB of 64, i.e. ONE path per wave; NROWS = 2: a wave covers 32 x 32 samples, one CTB of 32 (every chroma CTB
+ * of a 4:2:0 picture with 64-sample luma CTBs) -- the same, where 8-row lanes would spread a wave over four CTBs and run every
+ * path that occurs among them with a quarter of its lanes. */
+template <bool BORDER, int NROWS = 8, typename Fetch, typename Store>
 __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, int x, int y0, int w, int h, const DbkSaoCtb &c, bool kept)
 {
     if (kept || c.type == 0 || c.type > 2) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < NROWS; r++) {
             const SaoRaw q = fetch(r + 1);
             store(r, q.cx, q.cy);
         }
@@ -154,7 +158,7 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
             return apply(rec, band_sel(rec, 3, pos), tab_lo, tab_hi); /* 8 bit: bandShift = bitDepth - 5 = 3 */
         };
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < NROWS; r++) {
             const SaoRow m = unpack<false>(fetch(r + 1));
             store(r, band(m.E0) | (band(m.O0) << 8), band(m.E1) | (band(m.O1) << 8));
         }
@@ -163,10 +167,10 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
     /* edge offset: index 0 -> SaoOffsetVal[1], 1 -> [2], 2 -> none, 3 -> [3], 4 -> [4] */
     const uint32_t tab_lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (b(0) << 16) | (b(c.offset[2]) << 24), tab_hi = b(c.offset[3]);
     const int cls = c.cls & 3;
-    if (cls == 0) edge_rows<0, BORDER>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
-    else if (cls == 1) edge_rows<1, BORDER>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
-    else if (cls == 2) edge_rows<2, BORDER>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
-    else edge_rows<3, BORDER>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
+    if (cls == 0) edge_rows<0, BORDER, NROWS>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
+    else if (cls == 1) edge_rows<1, BORDER, NROWS>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
+    else if (cls == 2) edge_rows<2, BORDER, NROWS>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
+    else edge_rows<3, BORDER, NROWS>(fetch, store, x, y0, w, h, tab_lo, tab_hi);
 }
 
 } /* namespace sao8 */
@@ -222,13 +226,13 @@ __device__ __forceinline__ uint32_t apply(uint32_t rec, uint32_t idx /* + sao8::
 }
 using sao8::edge_idx;
 
-template <int CLS, bool BORDER, typename Fetch, typename Store>
+template <int CLS, bool BORDER, int NROWS, typename Fetch, typename Store>
 __device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store, int x, int y0, int w, int h, const Tab &t)
 {
     constexpr bool horizontal = CLS != 1, vertical = CLS != 0;
     Row up = unpack<horizontal>(fetch(0)), mid = unpack<horizontal>(fetch(1)), dn;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
+    for (int r = 0; r < NROWS; r++) {
         const int y = y0 + r;
         dn = unpack<horizontal>(fetch(r + 2));
         uint32_t i0, i1, i2, i3;
@@ -264,14 +268,15 @@ __device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store
     }
 }
 
-/* one 8x8 block of 16-bit samples; fetch(i) = raw row i = image row y0 - 1 + i; store(r, four dwords) */
-template <bool BORDER, typename Fetch, typename Store>
+/* one block of 8 x NROWS 16-bit samples (NROWS = 8, or 2 for 32-sample CTBs: see sao8::block); fetch(i) = raw row i = image
+ * row y0 - 1 + i; store(r, four dwords) */
+template <bool BORDER, int NROWS = 8, typename Fetch, typename Store>
 __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, int x, int y0, int w, int h, const DbkSaoCtb &c, bool kept,
                                       int max_v, int band_shift)
 {
     if (kept || c.type == 0 || c.type > 2) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < NROWS; r++) {
             const Raw q = fetch(r + 1);
             store(r, q.d[2], q.d[3], q.d[4], q.d[5]);
         }
@@ -289,7 +294,7 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
             return apply(rec, sao8::band_sel(rec, band_shift, pos), t);
         };
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < NROWS; r++) {
             const Raw q = fetch(r + 1);
             store(r, band(q.d[2]), band(q.d[3]), band(q.d[4]), band(q.d[5]));
         }
@@ -299,10 +304,10 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
     t.lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (0x80u << 16) | (b(c.offset[2]) << 24);
     t.hi = b(c.offset[3]);
     const int cls = c.cls & 3;
-    if (cls == 0) edge_rows<0, BORDER>(fetch, store, x, y0, w, h, t);
-    else if (cls == 1) edge_rows<1, BORDER>(fetch, store, x, y0, w, h, t);
-    else if (cls == 2) edge_rows<2, BORDER>(fetch, store, x, y0, w, h, t);
-    else edge_rows<3, BORDER>(fetch, store, x, y0, w, h, t);
+    if (cls == 0) edge_rows<0, BORDER, NROWS>(fetch, store, x, y0, w, h, t);
+    else if (cls == 1) edge_rows<1, BORDER, NROWS>(fetch, store, x, y0, w, h, t);
+    else if (cls == 2) edge_rows<2, BORDER, NROWS>(fetch, store, x, y0, w, h, t);
+    else edge_rows<3, BORDER, NROWS>(fetch, store, x, y0, w, h, t);
 }
 
 } /* namespace sao16 */
