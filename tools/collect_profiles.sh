@@ -28,6 +28,10 @@ run_stats() { # name, then the python script and its arguments
 run_stats bench_default_1gpu "$R/bench.py" --steps 200 --warmup 5 --traffic file --copy-floor off
 run_stats bench_8k10_1gpu "$R/bench.py" --traffic none --no-extra --copy-floor off --width 7680 --height 4320 --bit-depth 10 --frames 32
 run_stats bench_h265 "$R/tools/bench_h265.py"
+# what a decoder's operands cost: bS 0 / 1 / 2 mixed per segment, and a QP per 16x16 quantization group
+python3 "$R/tools/bench_h265.py" --only packed --bs mixed > "$OUT/bench_h265_decoder_operands.json" 2>/dev/null || true
+python3 "$R/tools/bench_h265.py" --only packed --qp-map 4 >> "$OUT/bench_h265_decoder_operands.json" 2>/dev/null || true
+python3 "$R/tools/bench_h265.py" --only packed --qp-map 4 --bs mixed >> "$OUT/bench_h265_decoder_operands.json" 2>/dev/null || true
 run_stats e2e_small "$R/tools/e2e_small.py" --file-frames 300 --sequence-frames 512
 run_stats bench_sao "$R/tools/bench_sao.py"
 python3 - "$OUT" <<'PY'
