@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--types", default="mix", help="mix (one third off / band / edge), off, band, edge: the SAO type of every CTB")
+    ap.add_argument("--ctb-log2", type=int, default=6, help="CTB size (6 = 64 samples; 5 = 32: the chroma planes of 4:2:0, or a stream with 32-sample CTBs)")
     ap.add_argument("--diag", default=None, help="run on libhevcdbk_diag.so with these knobs (noswz = the plain 3-D strip numbering)")
     a = ap.parse_args()
     if a.diag is not None:
@@ -26,7 +27,8 @@ def main():
     src = np.stack([synth.blocky_plane(w, h, seed=7, frame=i, bit_depth=bd) for i in range(4)])
     b.upload_all(np.concatenate([src] * (n // 4 + 1))[:n])
     rng = np.random.RandomState(5)
-    rows, cols = (h + 63) // 64, (w + 63) // 64
+    cs = 1 << a.ctb_log2
+    rows, cols = (h + cs - 1) // cs, (w + cs - 1) // cs
     prm = np.zeros((rows, cols), np.dtype(_lib.SAO_CTB_DTYPE))
     prm["type"] = rng.randint(0, 3, (rows, cols))
     if a.types != "mix":
@@ -37,16 +39,16 @@ def main():
     dp.upload(prm.view(np.uint8).ravel())
     p = b.planes()
     for _ in range(100):
-        ctx.sao_device(p, dp.ptr, cols, 6)
+        ctx.sao_device(p, dp.ptr, cols, a.ctb_log2)
     ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        ctx.sao_device(p, dp.ptr, cols, 6)
+        ctx.sao_device(p, dp.ptr, cols, a.ctb_log2)
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     nbytes = 2 * n * w * h * sb
     print(json.dumps({"stage": "sao", "ms_per_launch": dt * 1e3, "frames_per_s": n / dt, "GBps": nbytes / dt * 1e-9,
-                      "frac_of_8TBps": nbytes / dt / 8e12, "workload": "%dx%d %d-bit luma x %d, CTB types: %s" % (w, h, bd, n, a.types), "diag": a.diag}))
+                      "frac_of_8TBps": nbytes / dt / 8e12, "workload": "%dx%d %d-bit luma x %d, %d-sample CTBs, types: %s" % (w, h, bd, n, cs, a.types), "diag": a.diag}))
 
 
 if __name__ == "__main__":
