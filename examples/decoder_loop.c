@@ -33,7 +33,7 @@ int main(void)
     }
 
     /* picture planes, the output picture's planes, prediction data, bS arrays, SAO parameters: all in HBM */
-    void *y, *cb, *cr, *y_out, *cb_out, *cr_out, *flags, *mv0, *mv1, *ref0, *ref1, *vbs, *hbs, *cvbs, *chbs, *sao, *sao_cb, *sao_cr;
+    void *y, *cb, *cr, *y_out, *cb_out, *cr_out, *flags, *mv0, *mv1, *ref0, *ref1, *vbs, *hbs, *cvbs, *chbs, *sao, *sao_cb, *sao_cr, *qpy;
     CHECK(hevcdbk_device_malloc(ctx, (size_t)W * H, &y));
     CHECK(hevcdbk_device_malloc(ctx, (size_t)CW * CH, &cb));
     CHECK(hevcdbk_device_malloc(ctx, (size_t)CW * CH, &cr));
@@ -55,6 +55,9 @@ int main(void)
     CHECK(hevcdbk_device_malloc(ctx, sao_bytes, &sao));
     CHECK(hevcdbk_device_malloc(ctx, sao_bytes, &sao_cb));
     CHECK(hevcdbk_device_malloc(ctx, sao_bytes, &sao_cr));
+    /* QpY per 16x16 quantization group (cu_qp_delta): one map in luma units, read by all three planes */
+    const unsigned qg_x = (W + 15) / 16, qg_y = (H + 15) / 16;
+    CHECK(hevcdbk_device_malloc(ctx, (size_t)qg_x * qg_y, &qpy));
     /* a decoder's reconstruction kernels would have written all of these; fill them so the sketch runs */
     CHECK(hevcdbk_memset_d(ctx, y, 128, (size_t)W * H));
     CHECK(hevcdbk_memset_d(ctx, cb, 128, (size_t)CW * CH));
@@ -67,6 +70,7 @@ int main(void)
     CHECK(hevcdbk_memset_d(ctx, sao, 0, sao_bytes));
     CHECK(hevcdbk_memset_d(ctx, sao_cb, 0, sao_bytes));
     CHECK(hevcdbk_memset_d(ctx, sao_cr, 0, sao_bytes));
+    CHECK(hevcdbk_memset_d(ctx, qpy, 32, (size_t)qg_x * qg_y));
 
     /* 8.7.2.4 */
     hevcdbk_h265_units u;
@@ -89,9 +93,10 @@ int main(void)
         p[i].n_frames = 1; p[i].bit_depth = 8; p[i].sample_bytes = 1; p[i].is_chroma = i != 0;
         p[i].src = src[i]; p[i].dst = dst[i]; p[i].pitch = pw; p[i].frame_stride = (size_t)pw * ph; p[i].plane_w = pw; p[i].plane_h = ph;
         p[i].vert_bs = (const uint8_t *)(i ? cvbs : vbs); p[i].hor_bs = (const uint8_t *)(i ? chbs : hbs);
+        p[i].qp_map = (const uint8_t *)qpy; p[i].qp_map_stride = qg_x; p[i].ctu_log2 = 4; /* the map unit: 16 luma samples */
         so[i].params = (const hevcdbk_sao_ctb *)sp[i]; so[i].params_stride = ctbs_x; so[i].ctb_log2 = i ? 5 : 6;
     }
-    CHECK(hevc_deblock_sao_h265_device_planes(ctx, p, 3, 32, &prm, so, HEVCDBK_FUSED_AUTO, NULL));
+    CHECK(hevc_deblock_sao_h265_device_planes(ctx, p, 3, /* qp: unused with a map */ 0, &prm, so, HEVCDBK_FUSED_AUTO, NULL));
     /* a picture whose chroma SAO is switched off deblocks Cb / Cr in place instead:
      *   hevc_deblocking_filter_h265_device(ctx, &chroma_plane, c_idx, qp, &prm, HEVCDBK_KERNEL_AUTO, NULL) */
     CHECK(hevcdbk_synchronize(ctx));
@@ -102,7 +107,7 @@ int main(void)
     hevcdbk_device_free(ctx, flags); hevcdbk_device_free(ctx, mv0); hevcdbk_device_free(ctx, mv1);
     hevcdbk_device_free(ctx, ref0); hevcdbk_device_free(ctx, ref1);
     hevcdbk_device_free(ctx, vbs); hevcdbk_device_free(ctx, hbs); hevcdbk_device_free(ctx, cvbs); hevcdbk_device_free(ctx, chbs);
-    hevcdbk_device_free(ctx, sao);
+    hevcdbk_device_free(ctx, sao); hevcdbk_device_free(ctx, qpy);
     hevcdbk_destroy(ctx);
     return 0;
 }
