@@ -512,11 +512,14 @@ DBK_HD void normal_pairs(Taps &a, Taps &b, const K &k, pk m5, pk m6, int max_v, 
 /* one luma segment given its two unpacked pairs; returns false when nothing changed */
 /* ablate (diagnostic builds of the benchmark only, 0 in the product): 1 = treat strong segments as
  * normal, 2 = skip the normal filter -- wrong pixels, used to price each path on the GPU */
+/* enable: a per-lane switch that joins the filter decision (the spec-exact mode's bS == 0: a lane-level `if` AROUND this
+ * function nests its divergent region inside another one, and the compiler then initialises the twelve result registers
+ * with copies of the taps twice per segment -- 96 v_mov_b32 per block in the spec-exact kernels of round 3) */
 template <bool WIDE = false, bool UNI = true, class K>
-DBK_HD bool luma_pairs(Taps &a, Taps &b, const K &k, int max_v = 255, int ablate = 0)
+DBK_HD bool luma_pairs(Taps &a, Taps &b, const K &k, int max_v = 255, int ablate = 0, bool enable = true)
 {
     const Decision d = decide(a, k);
-    if (!d.filter) return false;
+    if (!(d.filter && enable)) return false;
     if (d.strong && ablate != 1) {
         strong_pair<WIDE, UNI>(a, k);
         strong_pair<WIDE, UNI>(b, k);

@@ -101,42 +101,63 @@ DBK_HD H265Uni h265_uni(int beta, int tc_bs1, int tc_bs2)
  * carries a keep flag (PCM / transquant bypass are rare, and a picture's edges are mostly intra = 2 or mostly inter = 1):
  * such a wave runs the SAME code as the reference-exact kernel -- decisions through saturating subtractions and biased
  * adds, the three-instruction strong clamp, one conservative |delta| test, operands in SGPRs -- with the standard's
- * thresholds and clip (LumaKLazy<true>).  A wave with both bS values runs that core with per-lane operands (LumaKEager); only
- * a wave with a keep flag takes the general per-lane form below.
+ * thresholds and clip (LumaKLazy<true>).  A wave with both bS values runs that core with per-lane operands (LumaKEager).
+ * Lanes with a keep flag take the general per-lane form further down.
+ *
+ * The forms are STAGES, one after the other, each behind a wave-uniform guard and each switched per lane (`enable`), all
+ * updating the taps in place -- not the arms of one if / else: as alternatives their results met in a twelve-register PHI
+ * that the compiler resolved with twelve copies at the end of the hot arm (and twelve more around a lane-level `if`): 96
+ * v_mov_b32 per block, the whole difference between this kernel's 786 VALU instructions per wave and the reference-exact
+ * kernel's 704.
  */
 template <bool WIDE = false>
 DBK_HD void luma_pairs_h265(Taps &a, Taps &b, int entry, int beta, int tc, int max_v);
+
+/* a wave-uniform flag the optimiser cannot relate to the expression it came from (two guards of opposite sense stay two
+ * `if`s instead of being fused into one if / else) */
+DBK_HD bool opaque_uniform(bool v)
+{
+#if DBK_DEV
+    int x = v ? 1 : 0;
+    asm volatile("" : "+v"(x));
+    return __builtin_amdgcn_readfirstlane(x) != 0;
+#else
+    return v;
+#endif
+}
+
 template <bool WIDE = false>
 DBK_HD void luma_pairs_h265_uni(Taps &a, Taps &b, int entry, int beta, int tc, int max_v, const H265Uni &u)
 {
     const int bs = entry & kH265BsMask;
-    const unsigned long long m1 = lane_ballot(bs == 1), m2 = lane_ballot(bs == 2);
-    const unsigned long long mk = lane_ballot(bs != 0 && (entry & (kH265KeepP | kH265KeepQ)) != 0);
-    if (mk == 0ull && (m1 == 0ull || m2 == 0ull)) {
+    const bool keep = (entry & (kH265KeepP | kH265KeepQ)) != 0;
+    if (any_lane(bs != 0 && keep)) luma_pairs_h265<WIDE>(a, b, keep ? entry : 0, beta, tc, max_v); /* entry 0: lane off */
+    const bool fast = bs != 0 && !keep;
+    const unsigned long long m1 = lane_ballot(fast && bs == 1), m2 = lane_ballot(fast && bs == 2);
+    const bool one_bs = m1 == 0ull || m2 == 0ull;
+    if ((m1 | m2) != 0ull && one_bs) {
         /* the wave's one tc is picked on the scalar unit and the segment constants are built from it right here */
-        if (bs != 0) luma_pairs<WIDE, true>(a, b, LumaKLazy<true>{u.beta, m2 != 0ull ? u.tc2 : u.tc1}, max_v);
-    } else if (mk == 0ull) {
+        luma_pairs<WIDE, true>(a, b, LumaKLazy<true>{u.beta, m2 != 0ull ? u.tc2 : u.tc1}, max_v, 0, fast);
+    }
+    if (opaque_uniform(!one_bs)) {
         /* bS 1 and bS 2 side by side (inter pictures): the same core with per-lane operands, as the QP-map kernels run it */
-        if (bs != 0) luma_pairs<WIDE, false>(a, b, LumaKEager::make<true>(beta, tc), max_v);
-    } else {
-        luma_pairs_h265<WIDE>(a, b, entry, beta, tc, max_v);
+        luma_pairs<WIDE, false>(a, b, LumaKEager::make<true>(beta, tc), max_v, 0, fast);
     }
 }
 
 /*
  * One luma segment, QP-map kernels: beta and tc differ from lane to lane anyway (tc already carries the lane's bS), so a
- * mix of bS values costs nothing; a wave in which no filtering lane carries a keep flag runs the shared core with per-lane
- * operands (LumaKEager, the standard's thresholds), any other wave the general form.
+ * mix of bS values costs nothing: the shared core with per-lane operands (LumaKEager, the standard's thresholds) for every
+ * lane without a keep flag, the general form for the others -- two stages, as above.
  */
 template <bool WIDE = false>
 DBK_HD void luma_pairs_h265_map(Taps &a, Taps &b, int entry, int beta, int tc, int max_v)
 {
     const int bs = entry & kH265BsMask;
-    if (lane_ballot(bs != 0 && (entry & (kH265KeepP | kH265KeepQ)) != 0) == 0ull) {
-        if (bs != 0) luma_pairs<WIDE, false>(a, b, LumaKEager::make<true>(beta, tc), max_v);
-    } else {
-        luma_pairs_h265<WIDE>(a, b, entry, beta, tc, max_v);
-    }
+    const bool keep = (entry & (kH265KeepP | kH265KeepQ)) != 0;
+    if (any_lane(bs != 0 && keep)) luma_pairs_h265<WIDE>(a, b, keep ? entry : 0, beta, tc, max_v);
+    const bool fast = bs != 0 && !keep;
+    if (any_lane(fast)) luma_pairs<WIDE, false>(a, b, LumaKEager::make<true>(beta, tc), max_v, 0, fast);
 }
 
 /* one luma segment from its two pairs; entry = bS byte with the keep flags; beta / tc already looked up */
