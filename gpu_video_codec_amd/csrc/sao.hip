@@ -193,6 +193,8 @@ using sao8::s_pk;
 using sao8::s_splat;
 
 typedef uint32_t sao_u32x4 __attribute__((ext_vector_type(4), aligned(4))); /* 16 bytes at a 4-byte-aligned address */
+typedef uint32_t sao_u32x2b __attribute__((ext_vector_type(2)));             /* operands of the raw buffer builtins */
+typedef uint32_t sao_u32x4b __attribute__((ext_vector_type(4)));
 
 /* HALO: the neighbours to the left / right take part.  INNER (wave-uniform): every lane's 16 bytes x-4 .. x+11 lie inside
  * the row, so the row is ONE 16-byte load per lane; otherwise three loads with the halo positions moved inside the row */
@@ -292,6 +294,38 @@ __global__ __launch_bounds__(64 * WAVES) void sao8_kernel(const DbkSaoArgs a, co
     uint8_t *dst = a.dst + (long long)f * a.frame_stride;
     const DbkSaoCtb c = a.params[(long long)f * a.params_frame_stride + (long long)(y0 >> a.ctb_log2) * a.params_stride + (x >> a.ctb_log2)];
     const bool kept = a.keep && a.keep[(long long)f * a.keep_frame_stride + (long long)(y0 >> 3) * a.keep_stride + (x >> 3)];
+    const bool border = x == 0 || x + 8 == a.plane_w || y0 == 0 || y0 + 8 >= a.plane_h;
+    if (__builtin_amdgcn_ballot_w64(border) == 0ull) {
+        /* no lane of the wave touches the picture border (nearly every wave): the shared block procedure (sao_packed.h, the
+         * edge class resolved once per block) on rows addressed through buffer resources -- a lane's byte offset once, the
+         * row in the scalar offset, no per-row 64-bit address arithmetic and no clamping of row numbers */
+        const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h; /* < 2^31: checked by the launcher */
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, plane_bytes, 0x00020000);
+        const int sp = __builtin_amdgcn_readfirstlane((int)a.pitch);
+        const uint32_t vrow = (uint32_t)y0 * (uint32_t)a.pitch + (uint32_t)x; /* (x, y0); y0 >= 8 and x >= 8 here */
+        const uint32_t vup = vrow - (uint32_t)a.pitch;                         /* raw row 0 = image row y0 - 1 */
+        auto fetch = [&](int j, auto halo) {
+            SaoRaw q;
+            if constexpr (decltype(halo)::value) {
+                const sao_u32x4b v = __builtin_amdgcn_raw_buffer_load_b128(rs, vup - 4u, j * sp, 0);
+                q.lh = v.x; q.cx = v.y; q.cy = v.z; q.rh = v.w;
+            } else {
+                const sao_u32x2b v = __builtin_amdgcn_raw_buffer_load_b64(rs, vup, j * sp, 0);
+                q.lh = q.rh = 0u;
+                q.cx = v.x; q.cy = v.y;
+            }
+            return q;
+        };
+        auto store = [&](int r, uint32_t lo, uint32_t hi) {
+            sao_u32x2b w;
+            w.x = lo;
+            w.y = hi;
+            __builtin_amdgcn_raw_buffer_store_b64(w, rd, vrow, r * sp, 0);
+        };
+        sao8::block<false, 8>(fetch, store, x, y0, a.plane_w, a.plane_h, c, kept);
+        return;
+    }
     if (kept || c.type == 0 || c.type > 2) {
 #pragma unroll
         for (int r = 0; r < 8; r++)
@@ -318,9 +352,7 @@ __global__ __launch_bounds__(64 * WAVES) void sao8_kernel(const DbkSaoArgs a, co
     }
     /* edge offset: index 0 -> SaoOffsetVal[1], 1 -> [2], 2 -> none, 3 -> [3], 4 -> [4] */
     const uint32_t tab_lo = b(c.offset[0]) | (b(c.offset[1]) << 8) | (b(0) << 16) | (b(c.offset[2]) << 24), tab_hi = b(c.offset[3]);
-    const bool border = x == 0 || x + 8 == a.plane_w || y0 == 0 || y0 + 8 >= a.plane_h;
-    if (__builtin_amdgcn_ballot_w64(border) != 0ull) sao8_edge_block<true>(a, src, dst, x, y0, c.cls & 3, tab_lo, tab_hi);
-    else sao8_edge_block<false>(a, src, dst, x, y0, c.cls & 3, tab_lo, tab_hi);
+    sao8_edge_block<true>(a, src, dst, x, y0, c.cls & 3, tab_lo, tab_hi); /* a wave with a lane on the picture border */
 }
 
 } /* namespace */
@@ -333,7 +365,8 @@ hipError_t dbk_launch_sao(const DbkSaoArgs &a, int sample_bytes, hipStream_t str
     if (g_dbk_diag.wg_cap == 64 || g_dbk_diag.wg_cap == 128) waves = g_dbk_diag.wg_cap / 64; /* A/B knob: narrower workgroups of the packed 8-bit kernel */
 #endif
     const bool aligned8 = a.pitch % 8 == 0 && a.frame_stride % 8 == 0 && ((uintptr_t)a.src % 8) == 0 && ((uintptr_t)a.dst % 8) == 0 &&
-                          a.plane_w % 8 == 0 && a.plane_h % 8 == 0 && a.max_v == 255 && a.band_shift == 3;
+                          a.plane_w % 8 == 0 && a.plane_h % 8 == 0 && a.max_v == 255 && a.band_shift == 3 &&
+                          (unsigned long long)a.pitch * (unsigned long long)a.plane_h < (1ull << 31); /* 32-bit buffer offsets */
     if (!(sample_bytes == 1 && aligned8)) waves = 4;
     const int strip_w = 64 * waves;
     const dim3 block(strip_w, 1, 1), grid3((a.plane_w + strip_w - 1) / strip_w, (a.plane_h + 63) / 64, a.n_frames);

@@ -7,6 +7,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "deblock_kernels.h"
 
 namespace sao8 {
@@ -93,11 +95,12 @@ __device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store
                                           uint32_t tab_hi)
 {
     constexpr bool horizontal = CLS != 1, vertical = CLS != 0;
-    SaoRow up = unpack<horizontal>(fetch(0)), mid = unpack<horizontal>(fetch(1)), dn;
+    constexpr std::bool_constant<horizontal> halo{}; /* tells the fetch functor whether the samples left / right of the block are looked at */
+    SaoRow up = unpack<horizontal>(fetch(0, halo)), mid = unpack<horizontal>(fetch(1, halo)), dn;
 #pragma unroll
     for (int r = 0; r < NROWS; r++) {
         const int y = y0 + r;
-        dn = unpack<horizontal>(fetch(r + 2));
+        dn = unpack<horizontal>(fetch(r + 2, halo));
         uint32_t i0, i1, i2, i3; /* indices of E0, O0, E1, O1 */
         if constexpr (CLS == 0) {
             i0 = edge_idx(mid.E0, mid.lE0, mid.O0);
@@ -135,7 +138,8 @@ __device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store
 
 /* one block of 8 x NROWS samples inside one CTB: not applied / kept (copy), band offset, or edge offset.  fetch(i) returns raw
  * row i = image row y0 - 1 + i (i = 0 .. NROWS + 1; the first and last are asked for by the edge classes only) -- from registers,
- * or from LDS as the rows are needed.  NROWS = 8: a lane's block is the keep map's unit and a wave (64 lanes) covers 64 x 64
+ * or from LDS as the rows are needed; its second argument (std::true_type / std::false_type) says whether the halo samples left
+ * and right of the block will be looked at (a functor that reads memory can fetch less when they are not).  NROWS = 8: a lane's block is the keep map's unit and a wave (64 lanes) covers 64 x 64
  * samples -- one CTB of 64, i.e. ONE path per wave; NROWS = 2: a wave covers 32 x 32 samples, one CTB of 32 (every chroma CTB
  * of a 4:2:0 picture with 64-sample luma CTBs) -- the same, where 8-row lanes would spread a wave over four CTBs and run every
  * path that occurs among them with a quarter of its lanes. */
@@ -145,7 +149,7 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
     if (kept || c.type == 0 || c.type > 2) {
 #pragma unroll
         for (int r = 0; r < NROWS; r++) {
-            const SaoRaw q = fetch(r + 1);
+            const SaoRaw q = fetch(r + 1, std::false_type{});
             store(r, q.cx, q.cy);
         }
         return;
@@ -159,7 +163,7 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
         };
 #pragma unroll
         for (int r = 0; r < NROWS; r++) {
-            const SaoRow m = unpack<false>(fetch(r + 1));
+            const SaoRow m = unpack<false>(fetch(r + 1, std::false_type{}));
             store(r, band(m.E0) | (band(m.O0) << 8), band(m.E1) | (band(m.O1) << 8));
         }
         return;
@@ -230,11 +234,12 @@ template <int CLS, bool BORDER, int NROWS, typename Fetch, typename Store>
 __device__ __forceinline__ void edge_rows(const Fetch &fetch, const Store &store, int x, int y0, int w, int h, const Tab &t)
 {
     constexpr bool horizontal = CLS != 1, vertical = CLS != 0;
-    Row up = unpack<horizontal>(fetch(0)), mid = unpack<horizontal>(fetch(1)), dn;
+    constexpr std::bool_constant<horizontal> halo{};
+    Row up = unpack<horizontal>(fetch(0, halo)), mid = unpack<horizontal>(fetch(1, halo)), dn;
 #pragma unroll
     for (int r = 0; r < NROWS; r++) {
         const int y = y0 + r;
-        dn = unpack<horizontal>(fetch(r + 2));
+        dn = unpack<horizontal>(fetch(r + 2, halo));
         uint32_t i0, i1, i2, i3;
         if constexpr (CLS == 0) {        /* (-1, 0) / (1, 0) */
             i0 = edge_idx(mid.P0, mid.L0, mid.L1);
@@ -277,7 +282,7 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
     if (kept || c.type == 0 || c.type > 2) {
 #pragma unroll
         for (int r = 0; r < NROWS; r++) {
-            const Raw q = fetch(r + 1);
+            const Raw q = fetch(r + 1, std::false_type{});
             store(r, q.d[2], q.d[3], q.d[4], q.d[5]);
         }
         return;
@@ -295,7 +300,7 @@ __device__ __forceinline__ void block(const Fetch &fetch, const Store &store, in
         };
 #pragma unroll
         for (int r = 0; r < NROWS; r++) {
-            const Raw q = fetch(r + 1);
+            const Raw q = fetch(r + 1, std::false_type{});
             store(r, band(q.d[2]), band(q.d[3]), band(q.d[4]), band(q.d[5]));
         }
         return;
