@@ -543,6 +543,18 @@ def extra_h265_stages(ctx, args, frames, batch, steps, wall_settled):
                      "ms_per_step": dt * 1e3, "frac": nbytes / dt / (HBM_PEAK_GBPS * 1e9), "achieved_GBps": nbytes / dt * 1e-9,
                      "algorithmic_bytes": nbytes, "steps": 4 * steps, "settle_ms": info["settle_ms"], "bit_exact_vs_oracle": ok,
                      "parity": "unpinned: checked against this repository's own restatement of H.265 8.7.3"}
+    # the same pass on parameters as a stream carries them: SAO merge flags copy the left / upper CTB's entry (here: left with
+    # probability 0.5, else up with 0.25), so neighbouring CTBs mostly take the same path -- the independent draw above is the
+    # worst case for a kernel that gives a wave one path
+    prm_m = h265.merge_sao_params(prm, seed=18)
+    dp.upload(prm_m.view(np.uint8).ravel())
+    dt, info = wall_settled(lambda: ctx.sao_device(ps, dp.ptr, prm.shape[1], 6), 4 * steps)
+    ok = bool(np.array_equal(batch.download_frame(Fs - 1), h265.sao_plane(frames[Fs - 1], prm_m, 6)))
+    out["sao_64_merged"] = {"workload": "SAO pass on %dx%d 8-bit luma, %d frames per launch, seeded per-CTB parameters merged from the left (p 0.5) / "
+                                        "upper (p 0.25) CTB as sao_merge_left_flag / sao_merge_up_flag do, src -> dst, wall clock per launch" % (w, h, Fs),
+                            "ms_per_step": dt * 1e3, "frac": nbytes / dt / (HBM_PEAK_GBPS * 1e9), "achieved_GBps": nbytes / dt * 1e-9,
+                            "algorithmic_bytes": nbytes, "steps": 4 * steps, "settle_ms": info["settle_ms"], "bit_exact_vs_oracle": ok,
+                            "parity": "unpinned: checked against this repository's own restatement of H.265 8.7.3"}
     dp.free()
     # spec-exact deblocking: bS 2 on every interior edge (4-sample granular arrays, shared by all frames)
     vb = np.zeros((h // 4, w // 8 + 1), np.uint8)

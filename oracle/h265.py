@@ -161,6 +161,22 @@ def sao_plane(plane, params, ctb_log2, *, bit_depth=8, keep=None):
     return dst
 
 
+def merge_sao_params(p, seed, p_left=0.5, p_up=0.25):
+    """What sao_merge_left_flag / sao_merge_up_flag do to a picture's parameters: in raster order a CTB takes its left
+    neighbour's entry with probability p_left, else the entry above with probability p_up, else keeps its own."""
+    rng = np.random.RandomState(seed)
+    out = p.copy()
+    rows, cols = out.shape
+    r = rng.random_sample((rows, cols, 2))
+    for y in range(rows):
+        for x in range(cols):
+            if x > 0 and r[y, x, 0] < p_left:
+                out[y, x] = out[y, x - 1]
+            elif y > 0 and r[y, x, 1] < p_up:
+                out[y, x] = out[y - 1, x]
+    return out
+
+
 def random_sao_params(w, h, ctb_log2, seed, bit_depth=8):
     rng = np.random.RandomState(seed)
     rows, cols = (h + (1 << ctb_log2) - 1) >> ctb_log2, (w + (1 << ctb_log2) - 1) >> ctb_log2

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--types", default="mix", help="mix (one third off / band / edge), off, band, edge: the SAO type of every CTB")
     ap.add_argument("--ctb-log2", type=int, default=6, help="CTB size (6 = 64 samples; 5 = 32: the chroma planes of 4:2:0, or a stream with 32-sample CTBs)")
+    ap.add_argument("--merge", action="store_true", help="merge the parameters from the left (p 0.5) / upper (p 0.25) CTB, as a stream's SAO merge flags do")
     ap.add_argument("--diag", default=None, help="run on libhevcdbk_diag.so with these knobs (noswz = the plain 3-D strip numbering)")
     a = ap.parse_args()
     if a.diag is not None:
@@ -35,6 +36,9 @@ def main():
         prm["type"] = {"off": 0, "band": 1, "edge": 2}[a.types]
     prm["cls"] = np.where(prm["type"] == 1, rng.randint(0, 32, (rows, cols)), rng.randint(0, 4, (rows, cols)))
     prm["offset"] = rng.randint(-7, 8, (rows, cols, 4))
+    if a.merge:
+        from oracle import h265
+        prm = h265.merge_sao_params(prm, seed=18)
     dp = ctx.alloc(prm.nbytes)
     dp.upload(prm.view(np.uint8).ravel())
     p = b.planes()
