@@ -289,21 +289,25 @@ __global__ __launch_bounds__(64 * WAVES) void sao8_kernel(const DbkSaoArgs a, co
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     /* Lane -> 8 x 8 block.  A wave takes one 64 x 64 region, i.e. with 64-sample CTBs one CTB and ONE path; its row pieces are
      * then 64 bytes, half a cache line.  Where the two CTBs of an aligned pair (waves 2k, 2k + 1 of the workgroup) take the
-     * same path -- the same type, and the same class if that is edge offset: SAO parameters are merged from the left / above
+     * same path -- both edge offset of one class, or neither edge offset: SAO parameters are merged from the left / above
      * neighbour in most CTBs of a real stream -- the two waves split the pair the other way: each takes 32 rows of BOTH CTBs
      * (16 blocks across, 4 down), whole 128-byte lines, still one path per wave.  (Round 3 measured the wide shape for every
      * pair: +8 % where the paths agree, -7 % where they differ; per pair it only ever takes the gain.) */
     int x = (wx * WAVES + wv) * 64 + (l & 7) * 8;
     int y0 = wy * 64 + (l >> 3) * 8;
+    bool zero_band = false;
     if constexpr (WAVES % 2 == 0) {
         const int px = (wx * WAVES + (wv & ~1)) * 64, py = wy * 64; /* the pair's origin */
         if (a.ctb_log2 == 6 && px + 128 <= a.plane_w && py + 64 <= a.plane_h) {
             const DbkSaoCtb *pc = a.params + (long long)f * a.params_frame_stride + (long long)(py >> 6) * a.params_stride + (px >> 6);
-            const int t0 = pc[0].type > 2 ? 0 : pc[0].type, t1 = pc[1].type > 2 ? 0 : pc[1].type;
-            const bool same = t0 == t1 && (t0 != 2 || ((pc[0].cls ^ pc[1].cls) & 3) == 0);
+            /* "not applied" and band offset count as one path: in a wide wave the former runs as a band offset of zeros (below) */
+            const bool e0 = pc[0].type == 2, e1 = pc[1].type == 2;
+            const bool same = e0 == e1 && (!e0 || ((pc[0].cls ^ pc[1].cls) & 3) == 0);
             if (__builtin_amdgcn_readfirstlane(same ? 1 : 0)) { /* uniform by construction: every lane looked at the same two entries */
                 x = px + (l & 15) * 8;
                 y0 = py + (wv & 1) * 32 + (l >> 4) * 8;
+                /* one CTB band offset, the other not applied: see below */
+                zero_band = __builtin_amdgcn_readfirstlane((!e0 && (pc[0].type == 1) != (pc[1].type == 1)) ? 1 : 0) != 0;
             }
         }
     }
@@ -341,6 +345,19 @@ __global__ __launch_bounds__(64 * WAVES) void sao8_kernel(const DbkSaoArgs a, co
             w.y = hi;
             __builtin_amdgcn_raw_buffer_store_b64(w, rd, vrow, r * sp, 0);
         };
+        if (zero_band) {
+            /* a wide wave over one band-offset CTB and one without SAO: the latter's blocks (and kept ones) run as a band offset
+             * of zeros (rec + 0, clipped: the same bytes) so that the two CTBs' lanes issue the SAME loads and stores -- whole
+             * lines -- instead of each half of the wave its own.  (A pair without SAO in either CTB keeps the plain copy:
+             * the arithmetic costs 5 % there.) */
+            DbkSaoCtb z = c;
+            if (kept || c.type != 1) {
+                z.type = 1; z.cls = 0;
+                z.offset[0] = z.offset[1] = z.offset[2] = z.offset[3] = 0;
+            }
+            sao8::block<false, 8>(fetch, store, x, y0, a.plane_w, a.plane_h, z, false);
+            return;
+        }
         sao8::block<false, 8>(fetch, store, x, y0, a.plane_w, a.plane_h, c, kept);
         return;
     }
