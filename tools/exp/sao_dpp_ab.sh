@@ -1,0 +1,4 @@
+for rep in 1 2 3; do for lib in build/exp/libhevcdbk_dpp.so gpu_video_codec_amd/libhevcdbk.so; do for t in "edge" "mix" "mix --merge"; do
+  echo -n "sao $t $(basename $lib) "; python3 tools/exp/run_with_lib.py $lib tools/bench_sao.py --types $t --steps 300 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_launch'],4), round(d['frac_of_8TBps'],3))"
+done; done; done
+python3 tools/exp/pytest_with_lib.py build/exp/libhevcdbk_dpp.so tests/test_gpu_h265.py -m gpu -x -q -k sao_on_device 2>&1 | tail -2
