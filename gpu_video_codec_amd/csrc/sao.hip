@@ -94,7 +94,7 @@ __device__ __forceinline__ bool sao_strip(const DbkFusedGrid &g, int &wx, int &w
  * CTB parameters and the keep flag are fetched once, and the edge classifier slides a three-row window down the block, so a
  * row is loaded once per lane (10 rows for 8 rows of output) instead of three times per output row.
  */
-template <typename T, bool SWZ>
+template <typename T, bool SWZ, bool PK16 = false> /* PK16: 16-bit containers up to 12 bit take the packed block procedure in waves off the border */
 __global__ __launch_bounds__(256) void sao_kernel(const DbkSaoArgs a, const DbkFusedGrid g)
 {
     /* a wave = the 8 x 8 blocks of one 64 x 64 region: with 64-sample CTBs every lane of a wave has the same SAO type and the
@@ -109,6 +109,44 @@ __global__ __launch_bounds__(256) void sao_kernel(const DbkSaoArgs a, const DbkF
     uint8_t *dst = a.dst + (long long)f * a.frame_stride;
     const DbkSaoCtb c = a.params[(long long)f * a.params_frame_stride + (long long)(y0 >> a.ctb_log2) * a.params_stride + (x >> a.ctb_log2)];
     const bool kept = a.keep && a.keep[(long long)f * a.keep_frame_stride + (long long)(y0 >> 3) * a.keep_stride + (x >> 3)];
+    if constexpr (PK16 && sizeof(T) == 2) {
+        /* no lane of the wave on the picture border (nearly every wave): the packed 16-bit block procedure of the fused kernels
+         * (sao_packed.h, sao16: the samples already are int16 pairs) on rows addressed through buffer resources, as the 8-bit
+         * kernel below does; a region's row piece is a whole 128-byte line here, so the wave keeps its 64 x 64 shape */
+        const bool border = x == 0 || x + 8 == a.plane_w || y0 == 0 || y0 + 8 >= a.plane_h;
+        if (__builtin_amdgcn_ballot_w64(border) == 0ull) {
+            typedef uint32_t u32x4b __attribute__((ext_vector_type(4)));
+            const uint32_t plane_bytes = (uint32_t)a.pitch * (uint32_t)a.plane_h; /* < 2^31: checked by the launcher */
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, plane_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, plane_bytes, 0x00020000);
+            const int sp = __builtin_amdgcn_readfirstlane((int)a.pitch);
+            const uint32_t vrow = (uint32_t)y0 * (uint32_t)a.pitch + (uint32_t)x * 2u;
+            const uint32_t vup = vrow - (uint32_t)a.pitch; /* raw row 0 = image row y0 - 1 */
+            auto fetch = [&](int j, auto halo) {
+                sao16::Raw q;
+                const u32x4b m = __builtin_amdgcn_raw_buffer_load_b128(rs, vup, j * sp, 0); /* samples x .. x+7 */
+                q.d[0] = q.d[7] = 0u;
+                q.d[2] = m.x; q.d[3] = m.y; q.d[4] = m.z; q.d[5] = m.w;
+                if constexpr (decltype(halo)::value) {
+                    q.d[1] = __builtin_amdgcn_raw_buffer_load_b32(rs, vup - 4u, j * sp, 0);  /* s[-2], s[-1] */
+                    q.d[6] = __builtin_amdgcn_raw_buffer_load_b32(rs, vup + 16u, j * sp, 0); /* s8, s9 */
+                } else {
+                    q.d[1] = q.d[6] = 0u;
+                }
+                return q;
+            };
+            auto store = [&](int r, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
+                u32x4b w;
+                w.x = d0; w.y = d1; w.z = d2; w.w = d3;
+                __builtin_amdgcn_raw_buffer_store_b128(w, rd, vrow, r * sp, 0);
+                /* the wait states of the fused 16-bit kernel's stores (deblock_sao_fused.inc): a 16-byte buffer store with an SGPR
+                 * offset followed at once by a VALU write of its data registers */
+                asm volatile("s_nop 1" : : "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w) : "memory");
+            };
+            sao16::block<false, 8>(fetch, store, x, y0, a.plane_w, a.plane_h, c, kept, a.max_v, a.band_shift);
+            return;
+        }
+    }
     if (kept || c.type == 0 || c.type > 2) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -435,7 +473,13 @@ hipError_t dbk_launch_sao(const DbkSaoArgs &a, int sample_bytes, hipStream_t str
         if (swz) hipLaunchKernelGGL((sao_kernel<uint8_t, true>), grid, block, 0, stream, a, g);
         else hipLaunchKernelGGL((sao_kernel<uint8_t, false>), grid, block, 0, stream, a, g);
     } else {
-        if (swz) hipLaunchKernelGGL((sao_kernel<uint16_t, true>), grid, block, 0, stream, a, g);
+        /* up to 12 bit (the packed procedure's int16 fields; SaoOffsetVal scaled as the standard does), planes the buffer
+         * resources can address: the packed path in every wave off the picture border */
+        const bool pk16 = a.max_v <= 4095 && a.band_shift >= 3 && (1 << (a.band_shift + 5)) - 1 == a.max_v && a.pitch % 4 == 0 &&
+                          a.frame_stride % 4 == 0 && ((uintptr_t)a.src % 4) == 0 && ((uintptr_t)a.dst % 4) == 0 && a.plane_w % 8 == 0 &&
+                          a.plane_h % 8 == 0 && (unsigned long long)a.pitch * (unsigned long long)a.plane_h < (1ull << 31);
+        if (swz && pk16) hipLaunchKernelGGL((sao_kernel<uint16_t, true, true>), grid, block, 0, stream, a, g);
+        else if (swz) hipLaunchKernelGGL((sao_kernel<uint16_t, true>), grid, block, 0, stream, a, g);
         else hipLaunchKernelGGL((sao_kernel<uint16_t, false>), grid, block, 0, stream, a, g);
     }
     return hipGetLastError();
