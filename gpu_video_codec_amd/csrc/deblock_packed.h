@@ -271,7 +271,10 @@ struct LumaKEager {
         const LumaKLazy<H265> z{beta, tc};
         LumaKEager k;
         k.filter_thr_ = z.filter_thr(); k.km_dpq_ = z.km_dpq(); k.km_e_ = z.km_e(); k.kf_ = z.kf(); k.side_thr_ = z.side_thr();
-        k.snegc_ = z.snegc(); k.nP_ = z.nP(); k.nmask_ = z.nmask(); k.strong_possible_ = z.strong_possible(); k.tc_zero_ = z.tc_zero();
+        k.snegc_ = z.snegc(); k.nP_ = z.nP(); k.nmask_ = z.nmask(); k.tc_zero_ = z.tc_zero();
+        /* per lane the three comparisons would cost five instructions per segment and decide nothing: a threshold of zero
+         * makes its bias 0x8000 - 0, which sets bit 15 of the biased field whatever the samples are (decide(): `bad`) */
+        k.strong_possible_ = true;
         k.sc2_ = z.sc2(); k.sk_ = z.sk(); k.nc_ = z.nc(); k.nnegc_ = z.nnegc(); k.nc2_ = z.nc2(); k.nnegc2_ = z.nnegc2(); k.nlim_ = z.nlim();
         return k;
     }
