@@ -39,6 +39,8 @@ EXPORTS = [
     "hevc_deblocking_filter_h265_device", "hevc_deblocking_filter_h265", "hevc_sao_filter_device",
     "hevc_deblock_sao_device", "hevc_deblock_sao_h265_device",
     "hevc_deblock_sao_device_planes", "hevc_deblock_sao_h265_device_planes",
+    "hevcdbk_set_host_threads", "hevcdbk_get_host_threads", "hevcdbk_host_register", "hevcdbk_host_unregister",
+    "hevcdbk_last_frame_trace",
 ]
 
 
@@ -59,6 +61,14 @@ class Qp(C.Structure):
 
 class Tables(C.Structure):
     _fields_ = [("tc", C.c_void_p), ("beta", C.c_void_p)]
+
+
+class StripTrace(C.Structure):
+    """hevcdbk_strip_trace: one strip of the last large-frame hevc_deblocking_filter call"""
+    _fields_ = [("plane", C.c_int), ("row_begin", C.c_uint), ("row_end", C.c_uint), ("bytes", C.c_size_t),
+                ("stage_begin_s", C.c_double), ("stage_end_s", C.c_double), ("enqueue_begin_s", C.c_double),
+                ("enqueue_end_s", C.c_double), ("d2h_seen_s", C.c_double), ("unstage_begin_s", C.c_double),
+                ("unstage_end_s", C.c_double), ("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double)]
 
 
 class SaoPlane(C.Structure):
@@ -207,6 +217,12 @@ def lib():
                                                      C.POINTER(SaoPlane), C.c_int, C.c_void_p]
         L.hevc_deblock_sao_h265_device_planes.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint, C.c_uint, C.POINTER(H265Params),
                                                           C.POINTER(SaoPlane), C.c_int, C.c_void_p]
+        L.hevcdbk_set_host_threads.argtypes = [C.c_void_p, C.c_uint]
+        L.hevcdbk_get_host_threads.argtypes = [C.c_void_p]
+        L.hevcdbk_get_host_threads.restype = C.c_uint
+        L.hevcdbk_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.hevcdbk_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
+        L.hevcdbk_last_frame_trace.argtypes = [C.c_void_p, C.POINTER(StripTrace), C.c_uint, C.POINTER(C.c_uint)]
         _lib = L
     return _lib
 

@@ -12,6 +12,8 @@
 #include "../../include/hevc_deblock.h"
 #include "deblock_kernels.h"
 
+namespace dbkh { class StageCrew; }
+
 struct Growable {
     void *p = nullptr;
     size_t cap = 0;
@@ -38,6 +40,13 @@ struct hevcdbk_context {
     const void *bs_default_at = nullptr;
     unsigned bs_default_w = 0, bs_default_h = 0;
     bool bs_default_chroma = false;
+    /* large pageable frames of the host-frame operator: the staging crew (host_crew.h), created at the first such call */
+    dbkh::StageCrew *crew = nullptr;
+    Growable dev_push; /* fine-grained HBM the crew writes the caller's rows into through the PCIe BAR (large-BAR devices) */
+    int large_bar = -1; /* hipDeviceAttributeIsLargeBar, asked once */
+    unsigned host_threads = 0; /* threads copying during a call, the caller included; 0 = default (4) */
+    std::vector<hevcdbk_strip_trace> trace; /* the strips of the last large-frame call (hevcdbk_last_frame_trace) */
+    std::vector<void *> registered; /* hevcdbk_host_register'ed ranges still registered: released with the context */
 };
 
 namespace dbkh {
@@ -52,7 +61,7 @@ int bind(hevcdbk_context *ctx);                                             /* h
 int grow_pinned(hevcdbk_context *ctx, Growable &g, size_t bytes);
 int grow_device(hevcdbk_context *ctx, Growable &g, size_t bytes);
 bool bad_depth(unsigned bit_depth, unsigned sample_bytes);
-bool is_pinned_host(const void *p);
+bool is_pinned_host(const void *p, void **dev_ptr = nullptr);
 int check_frame(const hevcdbk_frame &f, bool &chroma);
 int check_bs(const hevcdbk_bs *bs, unsigned W, unsigned H, bool chroma);
 int planes_to_args(const hevcdbk_device_planes *p, unsigned qp, const hevcdbk_tables *tables, DbkArgs &a);

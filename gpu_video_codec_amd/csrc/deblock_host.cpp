@@ -14,21 +14,25 @@
 #include <hip/hip_runtime_api.h>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "deblock_ctx.h"
+#include "host_crew.h"
 #ifdef HEVCDBK_DIAG
 #include "hevcdbk_diag.h"
 #endif
@@ -93,15 +97,18 @@ bool bad_depth(unsigned bit_depth, unsigned sample_bytes)
            (sample_bytes == 1 && bit_depth != 8);
 }
 
-/* true when [p, p+bytes) is page-locked host memory the GPU can DMA from directly */
-bool is_pinned_host(const void *p)
+/* true when p is page-locked host memory the GPU can DMA from directly; *dev_ptr (if asked for) = the address a KERNEL uses for
+ * it: the same as p for hipHostMalloc memory, possibly another for a hipHostRegister'ed range */
+bool is_pinned_host(const void *p, void **dev_ptr)
 {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
         (void)hipGetLastError(); /* ordinary malloc memory: not an error for us */
         return false;
     }
-    return at.type == hipMemoryTypeHost;
+    if (at.type != hipMemoryTypeHost) return false;
+    if (dev_ptr) *dev_ptr = at.devicePointer;
+    return true;
 }
 
 /* the checks every host-frame entry makes on a frame: depth, the reference's dimension rule (cpu.h:46-48, for the chroma
@@ -328,6 +335,108 @@ int launch_frame_fused(hevcdbk_context *ctx, const DbkArgs *args, int npl, unsig
     return HEVCDBK_OK;
 }
 
+/* threads that copy during a large pageable frame, the caller included: what the context was told (hevcdbk_set_host_threads), else 4
+ * (tools/ubench/host_stage.hip: the box's staging rate stops growing between 4 and 8 threads).  The product reads no environment;
+ * the diagnostic build takes HEVCDBK_HOST_THREADS / _STREAM_STORES / _AFFINITY for A/B runs. */
+bool crew_knob(const char *name, bool dflt)
+{
+#ifdef HEVCDBK_DIAG
+    if (const char *e = std::getenv(name)) return std::strtol(e, nullptr, 10) != 0;
+#else
+    (void)name;
+#endif
+    return dflt;
+}
+
+/* the strip size of the large-frame pipeline (diagnostic build: HEVCDBK_HOST_STRIP_KB overrides, for sweeps) */
+size_t crew_strip_bytes(size_t dflt)
+{
+#ifdef HEVCDBK_DIAG
+    if (const char *e = std::getenv("HEVCDBK_HOST_STRIP_KB")) {
+        const size_t kb = (size_t)std::strtoul(e, nullptr, 10);
+        if (kb >= 64) return kb << 10;
+    }
+#endif
+    return dflt;
+}
+
+size_t crew_first_strip_bytes(size_t dflt)
+{
+#ifdef HEVCDBK_DIAG
+    if (const char *e = std::getenv("HEVCDBK_HOST_FIRST_STRIP_KB")) {
+        const size_t kb = (size_t)std::strtoul(e, nullptr, 10);
+        if (kb >= 32) return kb << 10;
+    }
+#endif
+    return dflt;
+}
+
+unsigned crew_size(const hevcdbk_context *ctx)
+{
+    unsigned n = ctx->host_threads;
+#ifdef HEVCDBK_DIAG
+    if (n == 0)
+        if (const char *e = std::getenv("HEVCDBK_HOST_THREADS")) n = (unsigned)std::strtoul(e, nullptr, 10);
+#endif
+    if (n == 0) n = 4;
+    return n > 64 ? 64 : n;
+}
+
+/* The CPUs on the GPU's side of the host (sysfs local_cpulist of its PCI function) that this process may run on: the page-locked
+ * ring lives in that socket's memory (hipHostMalloc allocates next to the device), so the crew copies into / out of local DRAM and the
+ * DMA does not cross the socket link.  false = unknown: no restriction. */
+bool cpus_near_device(int device, cpu_set_t *out)
+{
+    if (!crew_knob("HEVCDBK_HOST_AFFINITY", true)) return false;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    for (char *c = bus; *c; c++) *c = (char)std::tolower((unsigned char)*c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    char line[4096] = {0};
+    const bool got = std::fgets(line, sizeof line, f) != nullptr;
+    std::fclose(f);
+    if (!got) return false;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    CPU_ZERO(out);
+    int n = 0;
+    for (char *p = line; *p && *p != '\n';) { /* "0-63,128-191" */
+        char *end = nullptr;
+        long a = std::strtol(p, &end, 10), b = a;
+        if (end == p) break;
+        if (*end == '-') { p = end + 1; b = std::strtol(p, &end, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, out); n++; }
+        p = *end == ',' ? end + 1 : end;
+        if (*end != ',' ) break;
+    }
+    return n > 0;
+}
+
+int ensure_crew(hevcdbk_context *ctx)
+{
+    const unsigned n = crew_size(ctx);
+    if (ctx->crew && ctx->crew->workers() + 1 == n) return HEVCDBK_OK;
+    delete ctx->crew;
+    ctx->crew = nullptr;
+    const bool stream = crew_knob("HEVCDBK_HOST_STREAM_STORES", true);
+    cpu_set_t near;
+    const bool have_near = cpus_near_device(ctx->device, &near);
+    try {
+        ctx->crew = new StageCrew(n - 1, stream, have_near ? &near : nullptr);
+    } catch (...) { /* thread creation failed */
+        ctx->crew = nullptr;
+        return HEVCDBK_ERR_NOMEM;
+    }
+    return HEVCDBK_OK;
+}
+
 } /* namespace dbkh */
 
 using namespace dbkh;
@@ -391,8 +500,10 @@ int hevcdbk_create(int device, hevcdbk_context **out)
 void hevcdbk_destroy(hevcdbk_context *ctx)
 {
     if (!ctx) return;
+    delete ctx->crew; /* joins the crew's threads (asleep between calls) */
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    for (void *p : ctx->registered) (void)hipHostUnregister(p);
     for (auto &g : ctx->pin) if (g.p) (void)hipHostFree(g.p);
     for (auto &g : ctx->dev) if (g.p) (void)hipFree(g.p);
     if (ctx->pin_bs.p) (void)hipHostFree(ctx->pin_bs.p);
@@ -400,6 +511,7 @@ void hevcdbk_destroy(hevcdbk_context *ctx)
     if (ctx->dev_map.p) (void)hipFree(ctx->dev_map.p);
     if (ctx->dev_units.p) (void)hipFree(ctx->dev_units.p);
     if (ctx->dev_tmp.p) (void)hipFree(ctx->dev_tmp.p);
+    if (ctx->dev_push.p) (void)hipFree(ctx->dev_push.p);
     if (ctx->tmp_ev) (void)hipEventDestroy(ctx->tmp_ev);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->timed_events) if (e) (void)hipEventDestroy(e);
@@ -480,6 +592,42 @@ int hevcdbk_host_free_pinned(hevcdbk_context *ctx, void *hptr)
     if (!ctx) return HEVCDBK_ERR_ARG;
     if (int rc = bind(ctx)) return rc;
     HIP_TRY(ctx, hipHostFree(hptr));
+    return HEVCDBK_OK;
+}
+int hevcdbk_host_register(hevcdbk_context *ctx, void *ptr, size_t bytes)
+{
+    if (!ctx || !ptr || bytes == 0) return HEVCDBK_ERR_ARG;
+    if (int rc = bind(ctx)) return rc;
+    HIP_TRY(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    ctx->registered.push_back(ptr);
+    return HEVCDBK_OK;
+}
+int hevcdbk_host_unregister(hevcdbk_context *ctx, void *ptr)
+{
+    if (!ctx || !ptr) return HEVCDBK_ERR_ARG;
+    if (int rc = bind(ctx)) return rc;
+    for (size_t i = 0; i < ctx->registered.size(); i++)
+        if (ctx->registered[i] == ptr) {
+            /* transfers of the host-frame operators have completed when they return; the streaming operator synchronises too */
+            HIP_TRY(ctx, hipHostUnregister(ptr));
+            ctx->registered.erase(ctx->registered.begin() + (long)i);
+            return HEVCDBK_OK;
+        }
+    return HEVCDBK_ERR_ARG; /* not registered through this context */
+}
+int hevcdbk_set_host_threads(hevcdbk_context *ctx, unsigned n_threads)
+{
+    if (!ctx || n_threads > 64) return HEVCDBK_ERR_ARG;
+    ctx->host_threads = n_threads; /* the crew is (re)built by the next large pageable frame */
+    return HEVCDBK_OK;
+}
+unsigned hevcdbk_get_host_threads(const hevcdbk_context *ctx) { return ctx ? crew_size(ctx) : 0; }
+int hevcdbk_last_frame_trace(const hevcdbk_context *ctx, hevcdbk_strip_trace *out, unsigned cap, unsigned *n_strips)
+{
+    if (!ctx || (!out && cap)) return HEVCDBK_ERR_ARG;
+    const size_t n = ctx->trace.size();
+    for (size_t i = 0; i < n && i < cap; i++) out[i] = ctx->trace[i];
+    if (n_strips) *n_strips = (unsigned)n;
     return HEVCDBK_OK;
 }
 int hevcdbk_memcpy_h2d(hevcdbk_context *ctx, void *dptr, const void *hptr, size_t bytes)
@@ -763,6 +911,7 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
         plane_off[i] = frame_bytes;
         frame_bytes = (frame_bytes + plane_bytes[i] + 255) & ~(size_t)255;
     }
+    ctx->trace.clear();
     if (int rc = grow_pinned(ctx, ctx->pin[0], frame_bytes)) return rc;
     if (int rc = grow_device(ctx, ctx->dev[0], frame_bytes)) return rc;
     uint8_t *hplane[3], *dplane_b[3];
@@ -816,16 +965,18 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
          */
         /* planes that are page-locked caller memory themselves (and word aligned) need no staging either */
         bool direct = true;
+        void *kplane[3] = {nullptr, nullptr, nullptr}; /* the planes as a kernel addresses them */
         for (int i = 0; i < npl && direct; i++)
-            direct = frame->pitch[i] % (4 * sb) == 0 && (uintptr_t)frame->plane[i] % (4 * sb) == 0 && is_pinned_host(frame->plane[i]);
+            direct = frame->pitch[i] % (4 * sb) == 0 && (uintptr_t)frame->plane[i] % (4 * sb) == 0 && is_pinned_host(frame->plane[i], &kplane[i]) &&
+                     kplane[i] != nullptr;
         if (!direct)
             for (int i = 0; i < npl; i++) {
                 const size_t rb = (size_t)pw[i] * sb;
                 for (unsigned r = 0; r < ph[i]; r++)
                     std::memcpy(hplane[i] + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
             }
-        void *hp[3] = {direct ? frame->plane[0] : (void *)hplane[0], direct ? frame->plane[1] : (void *)hplane[1],
-                       direct ? frame->plane[2] : (void *)hplane[2]};
+        void *hp[3] = {direct ? kplane[0] : (void *)hplane[0], direct ? kplane[1] : (void *)hplane[1],
+                       direct ? kplane[2] : (void *)hplane[2]};
         DbkArgs ha[3];
         for (int i = 0; i < npl; i++)
             if (int rc = frame_plane_args(ctx, hp, i, W, H, frame->bit_depth, sb, chroma, qp, dmap, tables, ha[i],
@@ -881,78 +1032,242 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
          * Large frame: strip pipeline.  Image rows 8b-4 .. 8b+3 belong to block row b and to no other, so a plane splits
          * into strips of whole block rows with no halo; strip s is uploaded, filtered (a launch over its block rows only)
          * and downloaded while strip s+1 is being packed / uploaded and strip s-1 downloaded: the two DMA directions, the
-         * kernels and the host-side staging copies all overlap inside ONE frame.
+         * kernels and the host-side staging copies all overlap inside ONE frame.  The first strips are short (the link is
+         * idle until the first one has been staged), later ones long enough for the DMA engines to reach their rate
+         * (tools/ubench/host_stage.hip: one 512 KiB DMA 19 us, 2 MiB 46 us, 8.3 MB 155 us).  Pageable planes are staged
+         * by the context's crew of host threads (host_crew.h) while this thread feeds the three streams.
          */
         struct Strip { int plane, b0, b1; unsigned r0, r1; };
         std::vector<Strip> strips;
+        bool any_staged = false;
+        /* The kernel writes its results straight into page-locked host memory -- the ring, or the caller's own page-locked plane when its
+         * rows are tight -- instead of into HBM with a D2H DMA behind it: posted writes across the link run at the DMA engines' rate
+         * (tools/ubench/host_stage.hip: 8.3 MB in 0.159 ms against 0.156 ms), and a DMA's set-up, two events and a cross-stream wait
+         * per strip disappear from the chain.  Pitched page-locked planes keep the 2-D DMA. */
+        const bool direct_out = crew_knob("HEVCDBK_HOST_DIRECT_OUT", true);
+        /* experiments of the diagnostic build (profiles/r04/experiments.md): all off in the product */
+        const bool x_direct_in = crew_knob("HEVCDBK_HOST_DIRECT_IN", false);
+        const int x_h2d_streams = crew_knob("HEVCDBK_HOST_H2D_STREAMS2", false) ? 2 : 1;
+        const int x_k_streams = crew_knob("HEVCDBK_HOST_K_STREAMS2", false) ? 2 : 1;
+        if (x_direct_in || x_h2d_streams == 2 || x_k_streams == 2) { /* the bS / QP map upload (on h2d) comes first on every stream used */
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[12], 0));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[12], 0));
+        }
+        /* Pageable planes on a large-BAR device: the crew writes the caller's rows straight into HBM through the BAR (posted writes,
+         * tools/ubench/bar_write.hip: 37-43 GB/s from one or two cores, as fast as filling the ring) -- no ring on the way in and no
+         * H2D DMA with its set-up, event and cross-stream wait per strip.  The buffer is fine-grained device memory, so no cache of the
+         * GPU holds a line of it across launches. */
+        if (ctx->large_bar < 0) {
+            int v = 0;
+            ctx->large_bar = hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, ctx->device) == hipSuccess && v ? 1 : 0;
+            (void)hipGetLastError();
+        }
+        bool push_in = direct_out && ctx->large_bar == 1 && crew_knob("HEVCDBK_HOST_PUSH", true);
+        uint8_t *kout[3] = {nullptr, nullptr, nullptr}; /* where the kernel of plane i writes (device-side address), NULL = HBM + DMA */
         for (int i = 0; i < npl; i++) {
+            any_staged |= !zc[i];
+            if (!direct_out) continue;
             const size_t rb = (size_t)pw[i] * sb;
-            const int nby = (int)(ph[i] / 8 + 1);
-            /* strips of about 2 MiB when a host-side staging copy rides along, 4 MiB when the DMA engines work alone */
-            int per = (int)((((size_t)(zc[i] ? 4 : 2) << 20) / rb) / 8);
-            per = per < 1 ? 1 : per;
-            for (int b0 = 0; b0 < nby; b0 += per) {
-                const int b1 = b0 + per < nby ? b0 + per : nby;
-                const unsigned r0 = b0 == 0 ? 0u : (unsigned)(8 * b0 - 4), r1 = b1 == nby ? ph[i] : (unsigned)(8 * b1 - 4);
-                strips.push_back({i, b0, b1, r0, r1});
+            void *dp = nullptr;
+            if (!zc[i]) kout[i] = hplane[i]; /* hipHostMalloc memory: one address for host and device */
+            else if (frame->pitch[i] == rb && (uintptr_t)frame->plane[i] % 4 == 0 && is_pinned_host(frame->plane[i], &dp) && dp)
+                kout[i] = (uint8_t *)dp;
+        }
+        {
+            /* strips: 256 KiB, then doubling up to `mid` (1.5 MiB when a copy-out rides along -- the crew, the link and the
+             * un-staging then work on three different strips at any time -- 2 MiB when the link works alone), the last `mid` of a
+             * frame cut in two so that little is left to do when the last transfer ends */
+            const size_t mid_staged = crew_strip_bytes((size_t)3 << 19), mid_locked = crew_strip_bytes((size_t)2 << 20);
+            size_t target = crew_first_strip_bytes((size_t)256 << 10);
+            for (int i = 0; i < npl; i++) {
+                const size_t rb = (size_t)pw[i] * sb, mid = zc[i] ? mid_locked : mid_staged;
+                const int nby = (int)(ph[i] / 8 + 1);
+                bool cut_tail = i == npl - 1; /* once, at the end of the frame */
+                for (int b0 = 0; b0 < nby;) {
+                    int per = (int)(((target < mid ? target : mid) / rb) / 8);
+                    per = per < 1 ? 1 : per;
+                    const int left = nby - b0;
+                    int take = per;
+                    if (left <= per + per / 2) { /* no sliver at the end of a plane */
+                        take = left;
+                        if (cut_tail && left > 2 && target >= mid) take = (2 * left + 2) / 3;
+                        cut_tail = false;
+                    }
+                    const int b1 = b0 + take;
+                    const unsigned r0 = b0 == 0 ? 0u : (unsigned)(8 * b0 - 4), r1 = b1 == nby ? ph[i] : (unsigned)(8 * b1 - 4);
+                    strips.push_back({i, b0, b1, r0, r1});
+                    b0 = b1;
+                    if (target < mid) target *= 2;
+                }
             }
         }
-        const size_t need = 6 * strips.size();
+        const size_t ns = strips.size();
+        const size_t need = 6 * ns;
         while (ctx->timed_events.size() < need) {
             hipEvent_t e;
             HIP_TRY(ctx, hipEventCreate(&e));
             ctx->timed_events.push_back(e);
         }
         hipEvent_t *te = ctx->timed_events.data(); /* per strip: h2d start/end, kernel start/end, d2h start/end */
-        for (size_t k = 0; k < strips.size(); k++) {
+        StageCrew *crew = nullptr;
+        uint8_t *dpush = nullptr;
+        if (any_staged || push_in) { /* page-locked caller planes are pushed too: faster than a chain of DMAs for ONE frame */
+            if (int rc = ensure_crew(ctx)) return rc;
+            crew = ctx->crew;
+            if (push_in && ctx->dev_push.cap < frame_bytes) {
+                if (ctx->dev_push.p) (void)hipFree(ctx->dev_push.p);
+                ctx->dev_push.p = nullptr; ctx->dev_push.cap = 0;
+                if (hipExtMallocWithFlags(&ctx->dev_push.p, frame_bytes, hipDeviceMallocFinegrained) == hipSuccess) ctx->dev_push.cap = frame_bytes;
+                else { (void)hipGetLastError(); ctx->dev_push.p = nullptr; push_in = false; } /* no such memory here: ring + DMA */
+            }
+            if (push_in) dpush = (uint8_t *)ctx->dev_push.p;
+        }
+                std::unique_ptr<CopyGroup[]> gin(new CopyGroup[ns]), gout(new CopyGroup[ns]);
+        /* every path out of this block waits for the jobs it handed out (they point into gin / gout) and puts the crew to sleep */
+        struct CrewScope {
+            StageCrew *c; CopyGroup *a, *b; size_t n;
+            ~CrewScope() { if (!c) return; for (size_t k = 0; k < n; k++) { c->wait(a[k]); c->wait(b[k]); } c->end(); }
+        } scope{crew, gin.get(), gout.get(), ns};
+        const int64_t ns0 = std::chrono::duration_cast<std::chrono::nanoseconds>(wall0.time_since_epoch()).count();
+        auto since = [ns0](int64_t t) { return t ? (double)(t - ns0) * 1e-9 : 0.0; };
+        ctx->trace.assign(ns, hevcdbk_strip_trace{});
+        /* a strip as row-range jobs for the crew: in = caller plane -> HBM (BAR) or ring, out = ring -> caller plane */
+        auto hand_out = [&](size_t k, bool in) {
+            const Strip &st = strips[k];
+            const int i = st.plane;
+            const size_t rb = (size_t)pw[i] * sb, bytes = (size_t)(st.r1 - st.r0) * rb;
+            /* pieces of at least 128 KiB: as many as there are crew threads -- two for writes through the BAR, which two cores saturate */
+            const unsigned crew_n = crew->workers() ? crew->workers() : 1, most = in && dpush && crew_n > 2 ? 2 : crew_n;
+            unsigned pieces = (unsigned)(bytes / ((size_t)128 << 10));
+            pieces = pieces < 1 ? 1 : pieces > most ? most : pieces;
+            CopyGroup &g = in ? gin[k] : gout[k];
+            g.pending.store((int)pieces, std::memory_order_release);
+            const unsigned rows = st.r1 - st.r0;
+            for (unsigned p = 0; p < pieces; p++) {
+                const unsigned a = st.r0 + (unsigned)((uint64_t)rows * p / pieces), b = st.r0 + (unsigned)((uint64_t)rows * (p + 1) / pieces);
+                uint8_t *ring = hplane[i] + (size_t)a * rb, *user = (uint8_t *)frame->plane[i] + (size_t)a * frame->pitch[i];
+                if (in && dpush) crew->submit({dpush + plane_off[i] + (size_t)a * rb, user, rb, frame->pitch[i], rb, b - a, &g, true}, StageCrew::LANE_IN);
+                else if (in) crew->submit({ring, user, rb, frame->pitch[i], rb, b - a, &g}, StageCrew::LANE_IN);
+                else crew->submit({user, ring, frame->pitch[i], rb, rb, b - a, &g}, StageCrew::LANE_OUT);
+            }
+        };
+        auto enqueue = [&](size_t k) -> int {
             const Strip &st = strips[k];
             const int i = st.plane;
             const size_t rb = (size_t)pw[i] * sb, off = (size_t)st.r0 * rb, bytes = (size_t)(st.r1 - st.r0) * rb;
-            if (!zc[i])
-                for (unsigned r = st.r0; r < st.r1; r++)
-                    std::memcpy(hplane[i] + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
-            if (timing) HIP_TRY(ctx, hipEventRecord(te[6 * k + 0], ctx->h2d));
-            if (zc[i])
-                HIP_TRY(ctx, hipMemcpy2DAsync((uint8_t *)dplane[i] + off, rb, (const uint8_t *)frame->plane[i] + (size_t)st.r0 * frame->pitch[i],
-                                              frame->pitch[i], rb, st.r1 - st.r0, hipMemcpyHostToDevice, ctx->h2d));
-            else
-                HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)dplane[i] + off, hplane[i] + off, bytes, hipMemcpyHostToDevice, ctx->h2d));
-            HIP_TRY(ctx, hipEventRecord(te[6 * k + 1], ctx->h2d));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, te[6 * k + 1], 0));
-            if (timing) HIP_TRY(ctx, hipEventRecord(te[6 * k + 2], ctx->compute));
+            hevcdbk_strip_trace &tr = ctx->trace[k];
+            tr.plane = i; tr.row_begin = st.r0; tr.row_end = st.r1; tr.bytes = bytes;
+            if (dpush || !zc[i]) {
+                tr.stage_begin_s = since(gin[k].first_ns.load());
+                tr.stage_end_s = since(gin[k].done_ns.load());
+            }
+            tr.enqueue_begin_s = since(crew_now_ns());
+            const bool tight = frame->pitch[i] == rb;
+            const bool pushed = dpush != nullptr; /* the strip is in HBM already: the crew wrote it there */
+            const bool din = pushed || (x_direct_in && kout[i]); /* (experiment: the kernel reads the page-locked strip itself) */
+            hipStream_t hs = x_h2d_streams == 2 && (k & 1) ? ctx->d2h : ctx->h2d;
+            hipStream_t ks = x_k_streams == 2 && (k & 1) ? ctx->d2h : ctx->compute;
+            if (!din) {
+                if (timing) HIP_TRY(ctx, hipEventRecord(te[6 * k + 0], hs));
+                if (zc[i] && !tight)
+                    HIP_TRY(ctx, hipMemcpy2DAsync((uint8_t *)dplane[i] + off, rb, (const uint8_t *)frame->plane[i] + (size_t)st.r0 * frame->pitch[i],
+                                                  frame->pitch[i], rb, st.r1 - st.r0, hipMemcpyHostToDevice, hs));
+                else
+                    HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)dplane[i] + off, (zc[i] ? (const uint8_t *)frame->plane[i] : hplane[i]) + off, bytes,
+                                                hipMemcpyHostToDevice, hs));
+                HIP_TRY(ctx, hipEventRecord(te[6 * k + 1], hs));
+                HIP_TRY(ctx, hipStreamWaitEvent(ks, te[6 * k + 1], 0));
+            }
             DbkArgs sa = args[i];
             sa.by_begin = st.b0;
             sa.by_count = st.b1 - st.b0;
-            if (int rc = launch(ctx, sa, (int)sb, i != 0, HEVCDBK_KERNEL_AUTO, ctx->compute)) return rc;
-            HIP_TRY(ctx, hipEventRecord(te[6 * k + 3], ctx->compute));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, te[6 * k + 3], 0));
-            if (timing) HIP_TRY(ctx, hipEventRecord(te[6 * k + 4], ctx->d2h));
-            if (zc[i])
-                HIP_TRY(ctx, hipMemcpy2DAsync((uint8_t *)frame->plane[i] + (size_t)st.r0 * frame->pitch[i], frame->pitch[i],
-                                              (uint8_t *)dplane[i] + off, rb, rb, st.r1 - st.r0, hipMemcpyDeviceToHost, ctx->d2h));
-            else
-                HIP_TRY(ctx, hipMemcpyAsync(hplane[i] + off, (uint8_t *)dplane[i] + off, bytes, hipMemcpyDeviceToHost, ctx->d2h));
-            HIP_TRY(ctx, hipEventRecord(te[6 * k + 5], ctx->d2h));
+            if (kout[i]) sa.dst = kout[i]; /* src: the strip in HBM; dst: page-locked host memory, same pitch */
+            if (pushed) sa.src = dpush + plane_off[i];
+            else if (din) sa.src = kout[i];
+            /* the launch stamps its own begin and end into the strip's events (one kernel per launch() in this library): no marker
+             * packets around the kernels, whose chain is what the frame waits for */
+            dbk_set_next_launch_events(timing ? te[6 * k + 2] : nullptr, te[6 * k + 3]);
+            const int lrc = launch(ctx, sa, (int)sb, i != 0, HEVCDBK_KERNEL_AUTO, ks);
+            dbk_set_next_launch_events(nullptr, nullptr);
+            if (lrc) return lrc;
+            if (!kout[i]) {
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, te[6 * k + 3], 0));
+                if (timing) HIP_TRY(ctx, hipEventRecord(te[6 * k + 4], ctx->d2h));
+                if (zc[i] && !tight)
+                    HIP_TRY(ctx, hipMemcpy2DAsync((uint8_t *)frame->plane[i] + (size_t)st.r0 * frame->pitch[i], frame->pitch[i],
+                                                  (uint8_t *)dplane[i] + off, rb, rb, st.r1 - st.r0, hipMemcpyDeviceToHost, ctx->d2h));
+                else
+                    HIP_TRY(ctx, hipMemcpyAsync((zc[i] ? (uint8_t *)frame->plane[i] : hplane[i]) + off, (uint8_t *)dplane[i] + off, bytes,
+                                                hipMemcpyDeviceToHost, ctx->d2h));
+                HIP_TRY(ctx, hipEventRecord(te[6 * k + 5], ctx->d2h));
+            }
+            tr.enqueue_end_s = since(crew_now_ns());
+            return HEVCDBK_OK;
+        };
+        /*
+         * One loop feeds everything, in strip order.  The copies-in of the whole frame go to the crew's first lane at once, so they run
+         * without a pause from the first microsecond; a strip whose copy-in is complete is handed to the runtime; a strip whose results
+         * have landed (event query, no blocking) goes to the crew's second lane for its copy-out.  This thread copies too until it has
+         * something to launch (the crew is still waking up then) and whenever there are no crew threads (hevcdbk_set_host_threads 1).
+         */
+        if (crew) crew->begin();
+        const bool alone = !crew || crew->workers() == 0;
+        size_t n_launched = 0, n_out = 0;
+        bool helped_once = false;
+        if (crew)
+            for (size_t k = 0; k < ns; k++)
+                if (dpush || !zc[strips[k].plane]) hand_out(k, true);
+        while (n_out < ns) {
+            bool progress = false;
+            if (n_launched < ns && ((!dpush && zc[strips[n_launched].plane]) || gin[n_launched].pending.load(std::memory_order_acquire) == 0)) {
+                if (int rc = enqueue(n_launched)) return rc;
+                n_launched++;
+                progress = true;
+            }
+            if (n_out < n_launched) {
+                const hipError_t q = hipEventQuery(te[6 * n_out + (kout[strips[n_out].plane] ? 3 : 5)]);
+                if (q == hipSuccess) {
+                    ctx->trace[n_out].d2h_seen_s = since(crew_now_ns());
+                    if (!zc[strips[n_out].plane]) hand_out(n_out, false);
+                    n_out++;
+                    progress = true;
+                } else if (q != hipErrorNotReady) {
+                    HIP_TRY(ctx, q);
+                } else {
+                    (void)hipGetLastError(); /* "not ready" is not an error */
+                }
+            }
+            if (progress) continue;
+            if (crew && (alone || !helped_once)) { /* the one job: the first piece of the first strip, while the crew wakes up */
+                helped_once = true;
+                if (crew->help()) continue;
+            }
+            _mm_pause();
         }
-        /* un-stage each strip as soon as its download has landed */
-        for (size_t k = 0; k < strips.size(); k++) {
-            const Strip &st = strips[k];
-            const int i = st.plane;
-            HIP_TRY(ctx, hipEventSynchronize(te[6 * k + 5]));
-            if (zc[i]) continue;
-            const size_t rb = (size_t)pw[i] * sb;
-            for (unsigned r = st.r0; r < st.r1; r++)
-                std::memcpy((uint8_t *)frame->plane[i] + r * frame->pitch[i], hplane[i] + r * rb, rb);
-        }
+        for (size_t k = 0; k < ns; k++)
+            if (!zc[strips[k].plane]) {
+                crew->wait(gout[k]);
+                ctx->trace[k].unstage_begin_s = since(gout[k].first_ns.load());
+                ctx->trace[k].unstage_end_s = since(gout[k].done_ns.load());
+            }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
+        if (x_k_streams == 2 || x_h2d_streams == 2) HIP_TRY(ctx, hipStreamSynchronize(ctx->d2h));
         const auto wall1s = std::chrono::steady_clock::now();
         if (timing) {
-            double copy = 0.0, exec = 0.0;
-            for (size_t k = 0; k < strips.size(); k++) {
+            double copy = 0.0, exec = 0.0, push_covered = 0.0;
+            for (size_t k = 0; k < ns; k++) {
                 float ms = 0.f;
-                HIP_TRY(ctx, hipEventElapsedTime(&ms, te[6 * k + 0], te[6 * k + 1])); copy += ms;
-                HIP_TRY(ctx, hipEventElapsedTime(&ms, te[6 * k + 2], te[6 * k + 3])); exec += ms;
-                HIP_TRY(ctx, hipEventElapsedTime(&ms, te[6 * k + 4], te[6 * k + 5])); copy += ms;
+                if (dpush) { /* the upload was the crew's stores through the BAR: host clock, the time during
+                                                        which at least one strip was being written (strips overlap) */
+                    const double b = ctx->trace[k].stage_begin_s, e = ctx->trace[k].stage_end_s;
+                    if (e > push_covered) copy += (e - (b > push_covered ? b : push_covered)) * 1e3;
+                    if (e > push_covered) push_covered = e;
+                } else if (!(x_direct_in && kout[strips[k].plane])) {
+                    HIP_TRY(ctx, hipEventElapsedTime(&ms, te[6 * k + 0], te[6 * k + 1])); copy += ms; ctx->trace[k].h2d_ms = ms;
+                }
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, te[6 * k + 2], te[6 * k + 3])); exec += ms; ctx->trace[k].kernel_ms = ms;
+                if (kout[strips[k].plane]) continue; /* the download is the kernel's own stores: part of exec_s */
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, te[6 * k + 4], te[6 * k + 5])); copy += ms; ctx->trace[k].d2h_ms = ms;
             }
             timing->exec_s = exec * 1e-3;   /* the reference's figures are sums of its serial phases (gpu.cu:1292-1303) */
             timing->copy_s = copy * 1e-3;

@@ -176,6 +176,33 @@ class Context:
         _chk(rc, self.handle)
         return {"exec_s": tm.exec_s, "total_s": tm.total_s, "copy_s": tm.copy_s, "pipelined_s": tm.pipelined_s}
 
+    # -- host side of filter_frame on large pageable frames --------------------------------------
+    def set_host_threads(self, n):
+        """Threads that copy between the caller's pageable planes and the page-locked ring during a large-frame
+        filter_frame call, the calling thread included (0 = the default, 4)."""
+        _chk(_lib.lib().hevcdbk_set_host_threads(self.handle, int(n)), self.handle)
+
+    def host_threads(self):
+        return int(_lib.lib().hevcdbk_get_host_threads(self.handle))
+
+    def host_register(self, arr):
+        """Page-locks the numpy array's memory in place (hevcdbk_host_register): planes inside it are DMA'd where they
+        lie by the host-frame operators.  Unregister before the array is freed."""
+        _chk(_lib.lib().hevcdbk_host_register(self.handle, arr.ctypes.data, arr.nbytes), self.handle)
+
+    def host_unregister(self, arr):
+        _chk(_lib.lib().hevcdbk_host_unregister(self.handle, arr.ctypes.data), self.handle)
+
+    def last_frame_trace(self):
+        """Per-strip record of the last large-frame filter_frame call (hevcdbk_last_frame_trace), a list of dicts."""
+        n = C.c_uint(0)
+        _chk(_lib.lib().hevcdbk_last_frame_trace(self.handle, None, 0, C.byref(n)), self.handle)
+        if n.value == 0:
+            return []
+        buf = (_lib.StripTrace * n.value)()
+        _chk(_lib.lib().hevcdbk_last_frame_trace(self.handle, buf, n.value, C.byref(n)), self.handle)
+        return [{f: getattr(t, f) for f, _ in _lib.StripTrace._fields_} for t in buf]
+
     # -- streaming operator on a sequence of host frames -----------------------------------------
     def pinned_array(self, shape, dtype=np.uint8):
         """numpy array in page-locked host memory (hevcdbk_host_malloc_pinned): planes allocated this way are

@@ -116,3 +116,95 @@ def gather_frame_results(dist, local, n_frames):
     if missing:
         raise RuntimeError("frames filtered by no rank: %s" % sorted(missing))
     return merged
+
+
+# ---- host topology: which CPUs sit next to which GPU (no HIP call: usable before the runtime is initialised) ----------
+
+def parse_cpulist(text):
+    """'0-63,128-191' -> {0..63, 128..191} (the format of sysfs cpulist files)."""
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-", 1)
+            cpus.update(range(int(a), int(b) + 1))
+        else:
+            cpus.add(int(part))
+    return cpus
+
+
+def gpu_pci_ids(sysfs_root="/sys"):
+    """PCI ids ('0000:c1:00.0') of the node's GPUs in the order the HIP runtime numbers them when no *_VISIBLE_DEVICES
+    variable filters them: the KFD topology nodes with SIMDs, in node order (location_id = bus << 8 | device << 3 | function)."""
+    base = os.path.join(sysfs_root, "class", "kfd", "kfd", "topology", "nodes")
+    ids = []
+    try:
+        nodes = sorted((n for n in os.listdir(base) if n.isdigit()), key=int)
+    except OSError:
+        return ids
+    for n in nodes:
+        props = {}
+        try:
+            with open(os.path.join(base, n, "properties")) as fh:
+                for line in fh:
+                    kv = line.split()
+                    if len(kv) == 2:
+                        props[kv[0]] = kv[1]
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) == 0:
+            continue  # a CPU node
+        loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        ids.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+    return ids
+
+
+def visible_device_index(local_index, env=None):
+    """The physical GPU behind HIP device `local_index` when HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES hold plain
+    index lists (anything else -- UUIDs -- is left alone: None)."""
+    env = os.environ if env is None else env
+    idx = local_index
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):  # HIP's list indexes into ROCR's
+        v = env.get(var)
+        if v is None or v == "":
+            continue
+        try:
+            lst = [int(x) for x in v.split(",")]
+        except ValueError:
+            return None
+        if not 0 <= idx < len(lst):
+            return None
+        idx = lst[idx]
+    return idx
+
+
+def cpus_near_gpu(local_index, sysfs_root="/sys", env=None):
+    """CPUs on the socket / NUMA node the GPU's host bridge hangs off (sysfs local_cpulist of its PCI function), or an
+    empty set when the topology cannot be read.  The page-locked staging memory of a rank lives in that node's DRAM, so a
+    rank that runs there copies locally and its DMA does not cross the socket link (host DRAM is what the 8
+    ranks of a node share)."""
+    phys = visible_device_index(local_index, env)
+    ids = gpu_pci_ids(sysfs_root)
+    if phys is None or not 0 <= phys < len(ids):
+        return set()
+    try:
+        with open(os.path.join(sysfs_root, "bus", "pci", "devices", ids[phys], "local_cpulist")) as fh:
+            return parse_cpulist(fh.read())
+    except (OSError, ValueError):
+        return set()
+
+
+def pin_to_gpu_cpus(local_index, sysfs_root="/sys"):
+    """Restrict this process to the CPUs near its GPU (intersected with what it may already use).  Call before the first HIP
+    call so that the runtime's helper threads inherit the mask.  Returns the sorted CPU list applied, or [] when nothing
+    was changed."""
+    near = cpus_near_gpu(local_index, sysfs_root)
+    if not near or not hasattr(os, "sched_setaffinity"):
+        return []
+    pick = os.sched_getaffinity(0) & near
+    if not pick:
+        return []
+    os.sched_setaffinity(0, pick)
+    return sorted(pick)

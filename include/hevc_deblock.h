@@ -139,6 +139,46 @@ HEVCDBK_API int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *fram
                            hevcdbk_timing *timing);
 
 /*
+ * Host side of hevc_deblocking_filter on a LARGE frame (> 2 MiB) in ordinary pageable memory -- the frame main.cu:112-133
+ * gets from ReadYuvFrame, where the reference copies row by row into cudaMallocHost planes on one thread, outside its
+ * timers (gpu.cu:1092-1133).  The frame is cut into strips of whole block rows (the first ones short, so the first DMA
+ * starts early); a crew of host threads copies strips into the page-locked ring while earlier strips are on the link, in
+ * the kernel or on their way back, and copies finished strips out.
+ *   hevcdbk_set_host_threads: how many threads copy during a call, the calling thread included (1 = the caller alone;
+ *   0 = the default, 4).  Crew threads are created at the first large pageable frame, run on the CPUs next to the GPU's
+ *   host bridge (sysfs local_cpulist) where the process is allowed to, sleep between calls and end with the context.
+ */
+HEVCDBK_API int hevcdbk_set_host_threads(hevcdbk_context *ctx, unsigned n_threads);
+HEVCDBK_API unsigned hevcdbk_get_host_threads(const hevcdbk_context *ctx);
+
+/*
+ * For callers that hand the same buffers in again and again (a decoder's picture pool): page-locks [ptr, ptr+bytes) in
+ * place (hipHostRegister; the reference's equivalent is allocating the planes with cudaMallocHost, gpu.cu:1092-1099).
+ * Planes inside a registered range are DMA'd where they lie, with no staging copy, by hevc_deblocking_filter,
+ * hevc_deblocking_filter_sequence and the h265 / SAO host entries.  The caller unregisters before freeing the memory.
+ */
+HEVCDBK_API int hevcdbk_host_register(hevcdbk_context *ctx, void *ptr, size_t bytes);
+HEVCDBK_API int hevcdbk_host_unregister(hevcdbk_context *ctx, void *ptr);
+
+/*
+ * Where the time of the LAST hevc_deblocking_filter call on a large frame went, strip by strip (measurement aid; the
+ * reference prints three sums, gpu.cu:1292-1303).  Host-clock fields are seconds since the call began; a field that does
+ * not apply (no staging for page-locked planes; GPU durations when the call had timing == NULL) is 0.
+ */
+typedef struct {
+    int plane;                 /* 0 Y, 1 U, 2 V */
+    unsigned row_begin, row_end;
+    size_t bytes;
+    double stage_begin_s, stage_end_s;     /* the crew's copy into the page-locked ring: first job began / last job ended */
+    double enqueue_begin_s, enqueue_end_s; /* H2D + kernel + D2H of the strip handed to the HIP runtime */
+    double d2h_seen_s;                     /* the calling thread saw the strip's download complete */
+    double unstage_begin_s, unstage_end_s; /* the crew's copy back into the caller's plane */
+    double h2d_ms, kernel_ms, d2h_ms;      /* GPU clock, between events on the three streams */
+} hevcdbk_strip_trace;
+/* copies min(cap, strips) entries to out (may be NULL with cap 0) and stores the strip count in *n_strips */
+HEVCDBK_API int hevcdbk_last_frame_trace(const hevcdbk_context *ctx, hevcdbk_strip_trace *out, unsigned cap, unsigned *n_strips);
+
+/*
  * Streaming form for a SEQUENCE of host frames of one geometry (the multi-frame case the reference does
  * not have).  Three frames are in flight: H2D of frame n+1, the kernels of frame n and
  * D2H of frame n-1 overlap on the context's three streams.  Planes that already are page-locked

@@ -269,3 +269,27 @@ def test_no_wide_store_is_overwritten_in_its_shadow():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_hazard.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "0 suspicious" in r.stdout
+
+
+def test_staging_crew_on_cpu_plain_and_under_thread_sanitizer():
+    """csrc/host_crew.h, the host threads that stage a large pageable frame of hevc_deblocking_filter: tests/host_crew/crew_test.cpp
+    runs strip-shaped copies (tight and pitched rows, 600 jobs through the 256-slot ring, 0..7 crew threads, streaming stores on
+    and off) and checks every byte, once as a plain build and once under -fsanitize=thread."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "host_crew")
+    subprocess.check_call(["make", "-s", "-C", d])
+    r = subprocess.run([os.path.join(d, "crew_test"), "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "0 failing rounds" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(d, "crew_test_tsan"), "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 failing rounds" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr[-3000:]
+
+
+def test_host_side_entries_reject_bad_arguments_without_a_device(L):
+    """The round-4 host-side entries take a context; with none they return HEVCDBK_ERR_ARG (no crash, no CPU path)."""
+    from gpu_video_codec_amd import _lib
+    n = C.c_uint(7)
+    assert L.hevcdbk_set_host_threads(None, 4) == _lib.ERR_ARG
+    assert L.hevcdbk_get_host_threads(None) == 0
+    assert L.hevcdbk_host_register(None, None, 0) == _lib.ERR_ARG
+    assert L.hevcdbk_host_unregister(None, None) == _lib.ERR_ARG
+    assert L.hevcdbk_last_frame_trace(None, None, 0, C.byref(n)) == _lib.ERR_ARG

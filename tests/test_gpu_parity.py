@@ -964,6 +964,78 @@ def test_strip_pipeline_on_large_frames_all_kernels(ctx, oracle):
                 assert np.array_equal(g, wnt), (bd, qmap is not None, nm)
 
 
+def test_staging_crew_sizes_on_large_pageable_frames(ctx, oracle):
+    """hevc_deblocking_filter on large frames in ordinary pageable memory with 1, 2, 4 and 8 copying threads (the caller
+    alone ... the crew of host_crew.h): a 4K luma frame in tight rows (block copies with streaming stores) and a 1080p 4:2:0
+    frame in pitched rows; results, the untouched row padding, and the strip record of the call (hevcdbk_last_frame_trace:
+    the strips tile every plane exactly, first strips shorter than later ones, all phases in order)."""
+    from gpu_video_codec_amd import synth
+    y4k = synth.blocky_plane(3840, 2160, seed=81)
+    want4k = oracle.filter_plane(y4k, 32, threads=8)
+    y, u, v = synth.blocky_yuv420(1920, 1088, seed=82)
+    want = oracle.split_yuv420(oracle.filter_yuv420(oracle.join_yuv420(y, u, v), 1920, 1088, 36), 1920, 1088)
+    try:
+        for n in (1, 2, 4, 8):
+            ctx.set_host_threads(n)
+            assert ctx.host_threads() == n
+            for rep in range(3):  # the crew sleeps between calls and is woken again
+                g = y4k.copy()
+                t = ctx.filter_frame(g, qp=32)
+                assert np.array_equal(g, want4k), (n, rep)
+            tr = ctx.last_frame_trace()
+            assert len(tr) >= 4 and tr[0]["row_begin"] == 0 and tr[-1]["row_end"] == 2160
+            assert all(a["row_end"] == b["row_begin"] for a, b in zip(tr, tr[1:]))
+            assert sum(s["bytes"] for s in tr) == y4k.nbytes and tr[0]["bytes"] < tr[-2]["bytes"]
+            for s in tr:
+                assert 0 < s["stage_begin_s"] <= s["stage_end_s"] <= s["enqueue_end_s"] <= s["d2h_seen_s"] <= s["unstage_end_s"] <= t["pipelined_s"], s
+                assert s["kernel_ms"] > 0 and s["d2h_ms"] == 0   # the kernel stores into the ring itself: no D2H DMA
+            bufs = []
+            for p in (y, u, v):
+                b = np.full((p.shape[0], p.shape[1] + 48), 0x3C, np.uint8)
+                b[:, :p.shape[1]] = p
+                bufs.append(b)
+            ctx.filter_frame(*[b[:, :p.shape[1]] for b, p in zip(bufs, (y, u, v))], qp=36)
+            for b, p, wnt in zip(bufs, (y, u, v), want):
+                assert np.array_equal(b[:, :p.shape[1]], wnt), n
+                assert (b[:, p.shape[1]:] == 0x3C).all(), n
+            assert {s["plane"] for s in ctx.last_frame_trace()} == {0, 1, 2}
+        ctx.filter_frame(*[p.copy() for p in synth.blocky_yuv420(352, 288, seed=3)], qp=30)
+        assert ctx.last_frame_trace() == []   # a small frame has no strips
+    finally:
+        ctx.set_host_threads(0)
+
+
+def test_registered_caller_memory_is_filtered_in_place(ctx, oracle):
+    """hevcdbk_host_register: a caller that reuses its buffers page-locks them once; the host-frame operator then DMAs the planes
+    where they lie or stores into them from the kernel (the strip record carries no un-stage times), tight and pitched, several frames through
+    the same buffer; unregistering twice is an argument error, and the buffer still works as pageable memory afterwards."""
+    from gpu_video_codec_amd import synth, deblock, _lib
+    w, h = 3840, 2160
+    buf = np.empty((h, w + 128), np.uint8)
+    ctx.host_register(buf)
+    try:
+        for seed, view in ((91, buf[:, :w]), (92, buf.reshape(-1)[: w * h].reshape(h, w)), (93, buf[:, :w])):
+            y = synth.blocky_plane(w, h, seed=seed)
+            buf[:] = 0x77
+            view[:] = y
+            ctx.filter_frame(view, qp=34)
+            assert np.array_equal(view, oracle.filter_plane(y, 34, threads=8)), seed
+            tr = ctx.last_frame_trace()
+            assert tr and all(s["unstage_end_s"] == 0 for s in tr), seed   # results are never copied out of a ring by the host
+            if view.strides[0] != w:
+                assert (buf[:, w:] == 0x77).all()
+    finally:
+        ctx.host_unregister(buf)
+    with pytest.raises(deblock.DeblockError) as e:
+        ctx.host_unregister(buf)
+    assert e.value.code == _lib.ERR_ARG
+    y = synth.blocky_plane(w, h, seed=94)
+    buf[:, :w] = y
+    ctx.filter_frame(buf[:, :w], qp=34)
+    assert np.array_equal(buf[:, :w], oracle.filter_plane(y, 34, threads=8))
+    assert all(s["unstage_end_s"] > 0 for s in ctx.last_frame_trace())   # pageable again: results come back through the ring
+
+
 def test_cpp_class_mirror_against_golden_manifest(manifest, tmp_path):
     """examples/read_yuv_frame.cpp = the reference's ExecuteCpu body on hevcdbk::ReadYuvFrame (include/hevc_deblock.hpp):
     ctor -> [SetBoundaryStrenght with the seeded generator] -> DeblockingFilter -> Save, against the reference's own hashes."""
