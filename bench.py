@@ -53,14 +53,22 @@ def algorithmic_bytes_per_frame(w, h, sample_bytes):
     return 2 * w * h * sample_bytes + deblock.num_vert_bs(w, h) + deblock.num_hor_bs(w, h)
 
 
-def make_frames(w, h, n, bit_depth, seed=1, n_base=4):
-    """n distinct frames: n_base generated frames x grid-aligned circular shifts (multiples of 8)."""
-    base = [synth.blocky_plane(w, h, seed=seed, frame=i, bit_depth=bit_depth) for i in range(min(n_base, n))]
-    out = np.empty((n, h, w), base[0].dtype)
-    for f in range(n):
-        b = base[f % len(base)]
-        k = f // len(base)
-        out[f] = np.roll(b, (8 * (5 * k % (h // 8)), 8 * (7 * k % (w // 8))), axis=(0, 1))
+def make_frames(w, h, n, bit_depth, seed=1, n_base=4, indices=None):
+    """Distinct frames of ONE seeded set: n_base generated frames x grid-aligned circular shifts (multiples of 8).  Frame g of the
+    set depends on (seed, g) alone; `indices` picks the frames a rank owns (default 0 .. n-1), so an N-rank job filters the
+    very frames a 1-rank job of the same total would."""
+    idx = list(range(n)) if indices is None else list(indices)   # n = frames in the whole set
+    nb = max(1, min(n_base, n))
+    base = {}
+    out = None
+    for j, f in enumerate(idx):
+        if f % nb not in base:
+            base[f % nb] = synth.blocky_plane(w, h, seed=seed, frame=f % nb, bit_depth=bit_depth)
+        b = base[f % nb]
+        if out is None:
+            out = np.empty((len(idx), h, w), b.dtype)
+        k = f // nb
+        out[j] = np.roll(b, (8 * (5 * k % (h // 8)), 8 * (7 * k % (w // 8))), axis=(0, 1))
     return out
 
 
@@ -377,6 +385,9 @@ def extra_configs(ctx, args, frames, batch, variant):
     # (2c) the SAO pass alone and the spec-exact deblocking kernel on 64 luma frames (both parity-unpinned stages)
     if bd == 8:
         out.update(extra_h265_stages(ctx, args, frames, batch, steps, wall_settled))
+    # (2d) BASELINE configs 1 and 3 on the reference's bundled inputs
+    if bd == 8:
+        out.update(extra_baseline_configs(ctx, args, frames, batch, steps, wall_settled))
 
     # (3) BASELINE config 5: 7680x4320 10-bit luma in 16-bit containers
     if not args.no_config5:
@@ -522,6 +533,142 @@ def extra_deblock_sao(ctx, args, frames, batch, cb, steps, wall_settled):
     return out
 
 
+def extra_baseline_configs(ctx, args, frames, batch, steps, wall_settled):
+    """BASELINE configs 1 and 3 on the reference's own bundled inputs (tests/golden), as lines of the driver's record:
+      config1_image1_cpu_1t      image1 352x288 luma, QP 30, the single-thread CPU path (main.cu:112-117: the checker, and the
+                                 reference's own header where oracle/_ref travelled); the HIP result of the same call against
+                                 the reference-made luma hash df8e3f17...;
+      config3_image2_bs_qpmap    image2 768x576 luma, bS drawn from {0,1,2} by the reference-harness LCG (main.cu:120-125
+                                 geometry): (3a) one QP 30 -- reference-pinned: seed 12345 against the reference-made hash, seed
+                                 2024 against the pinned checker -- and (3b) a QP per 64x64 CTU (12 x 9 map: this build's own
+                                 definition, parity unpinned); microseconds per device-resident call; plus the same operands at
+                                 benchmark size (64 x 4K, QP +-6 per CTU, LCG bS) with their fraction of the HBM roofline."""
+    import hashlib
+    from oracle import oracle
+    out = {}
+    gold = os.path.join(ROOT, "tests", "golden")
+    try:
+        with open(os.path.join(gold, "manifest.json")) as fh:
+            man = json.load(fh)["images"]
+        with open(os.path.join(gold, "image1_352x288_yv12.yuv"), "rb") as fh:
+            img1 = fh.read()
+        with open(os.path.join(gold, "image2_768x576.yuv"), "rb") as fh:
+            img2 = fh.read()
+    except (OSError, ValueError, KeyError):
+        return out
+
+    def luma_sha(name, qp, seed):
+        for c in man[name]["cases"]:
+            if c["qp"] == qp and c["bs_seed"] == seed:
+                return c["luma_sha256"]
+        return None
+
+    def device_call(y, qp, bs=None, qmap=None):
+        """one device-resident frame: (seconds per call after settling, the filtered plane)"""
+        b = deblock.DeviceBatch(ctx, y.shape[1], y.shape[0], 1, per_frame_bs=False)
+        b.upload_all(y[None])
+        if bs is not None:
+            b.set_bs(0, *bs)
+        if qmap is not None:
+            b.set_qp_map(qmap, 6)
+        p = b.planes()
+        dt, _i = wall_settled(lambda: ctx.filter_device(p, 0 if qmap is not None else qp), 200, min_ms=20.0, max_ms=200.0)
+        got = b.download_frame(0)
+        b.free()
+        return dt, got
+
+    # ---- config 1
+    y1, _u, _v = oracle.split_yuv420(img1, 352, 288)
+    ts = []
+    for _ in range(31):
+        fr = oracle.Frame(y1)
+        a = time.perf_counter()
+        fr.filter(30, planes=oracle.PLANE_Y, threads=1)
+        ts.append(time.perf_counter() - a)
+        fr.close()
+    dt1, got1 = device_call(y1, 30)
+    want_sha = luma_sha("image1", 30, None)
+    c1 = {"workload": "image1_352x288_yv12.yuv luma, QP 30, default bS (main.cu:112-117)",
+          "cpu_port_1t_median_s": float(np.median(ts[1:])), "cpu_port_1t_min_s": float(min(ts[1:])),
+          "gpu_device_resident_us_per_call": dt1 * 1e6, "reference_luma_sha256": want_sha,
+          "checker_matches_reference_sha": hashlib.sha256(oracle.filter_plane(y1, 30).tobytes()).hexdigest() == want_sha,
+          "bit_exact_vs_oracle": hashlib.sha256(got1.tobytes()).hexdigest() == want_sha,
+          "parity": "pinned: the hash was made by the reference's own header (tests/golden/make_golden.py)"}
+    try:
+        if oracle.have_ref():
+            tr = []
+            for _ in range(11):
+                rf = oracle.RefFrame(img1, 352, 288, 30)
+                a = time.perf_counter()
+                rf.filter(1)
+                tr.append(time.perf_counter() - a)
+                rf.close()
+            c1["cpu_reference_yuv420_1t_median_s"] = float(np.median(tr[1:]))
+    except Exception as e:  # optional evidence
+        c1["reference_error"] = str(e)
+    out["config1_image1_cpu_1t"] = c1
+
+    # ---- config 3 on the bundled 768x576 file
+    y2, _u, _v = oracle.split_yuv420(img2, 768, 576)
+    bs_a, bs_b = oracle.lcg_bs(768, 576, 12345), oracle.lcg_bs(768, 576, 2024)
+    dt_a, got_a = device_call(y2, 30, bs=bs_a)
+    dt_b, got_b = device_call(y2, 30, bs=bs_b)
+    qmap = synth.ctu_qp_map(768, 576, seed=7)
+    dt_m, got_m = device_call(y2, 0, bs=bs_b, qmap=qmap)
+    sha_a = luma_sha("image2", 30, 12345)
+    ok_a = hashlib.sha256(got_a.tobytes()).hexdigest() == sha_a
+    ok_b = bool(np.array_equal(got_b, oracle.filter_plane(y2, 30, vert_bs=bs_b[0], hor_bs=bs_b[1])))
+    ok_m = bool(np.array_equal(got_m, oracle.filter_plane(y2, 0, vert_bs=bs_b[0], hor_bs=bs_b[1], qp_map=qmap)))
+    c3 = {"workload": "image2_768x576.yuv luma, bS in {0,1,2} from the harness LCG (main.cu:120-125 geometry), device-resident, one frame per call",
+          "scalar_qp30_us_per_call": dt_b * 1e6, "scalar_qp30_seed12345_us_per_call": dt_a * 1e6, "ctu_qp_map_12x9_us_per_call": dt_m * 1e6,
+          "scalar_qp30_seed12345_matches_reference_sha": ok_a, "scalar_qp30_seed2024_matches_checker": ok_b,
+          "ctu_qp_map_matches_checker": ok_m, "bit_exact_vs_oracle": ok_a and ok_b and ok_m,
+          "parity": "scalar QP: pinned (reference-made hash for seed 12345; the pinned checker for seed 2024); QP map: unpinned -- the "
+                    "reference has one QP per frame (cpu.h:136-137), the map's semantics are this build's (DESIGN.md 2)"}
+    # ---- the same operands at benchmark size: 64 x 4K luma, LCG bS, QP +-6 per 64x64 CTU (the worst case) and a slowly varying map
+    w, h, qp = args.width, args.height, args.qp
+    if args.bit_depth == 8 and args.frames >= 64:
+        n = 64
+        b = deblock.DeviceBatch(ctx, w, h, n, per_frame_bs=False, storage=(batch.src, batch.dst))
+        bs4k = oracle.lcg_bs(w, h, 9)
+        b.set_bs(0, *bs4k)
+        p = b.planes()
+        nb = n * (2 * w * h + bs4k[0].size + bs4k[1].size)
+        dt, _i = wall_settled(lambda: ctx.filter_device(p, qp, variant=_lib.KERNEL_PACKED), 4 * steps)
+        ok = bool(np.array_equal(b.download_frame(n - 1), oracle.filter_plane(frames[n - 1], qp, vert_bs=bs4k[0], hor_bs=bs4k[1], threads=8)))
+        c3["luma_64x4k_lcg_bs_one_qp"] = {"ms_per_step": dt * 1e3, "frac": nb / dt / (HBM_PEAK_GBPS * 1e9), "algorithmic_bytes": nb,
+                                          "bit_exact_vs_oracle": ok}
+        for key, qm, memo in (("luma_64x4k_lcg_bs_qp_per_ctu", synth.ctu_qp_map(w, h, seed=29, lo=max(qp - 6, 0), hi=min(qp + 6, 51), ctu_log2=6),
+                               "QP drawn independently per 64x64 CTU, +-6 (worst case: nearly every wave mixes QPs)"),
+                              ("luma_64x4k_lcg_bs_qp_smooth", smooth_qp_map(w, h, qp),
+                               "QP per 64x64 CTU varying slowly across the picture (rate control's usual shape: +-3 over the frame)")):
+            b.set_qp_map(qm, 6)
+            p = b.planes()
+            nbm = nb + n * qm.size
+            dt, _i = wall_settled(lambda: ctx.filter_device(p, 0, variant=_lib.KERNEL_PACKED), 4 * steps)
+            ok = bool(np.array_equal(b.download_frame(n - 1), oracle.filter_plane(frames[n - 1], 0, vert_bs=bs4k[0], hor_bs=bs4k[1],
+                                                                                  qp_map=qm, ctu_log2=6, threads=8)))
+            c3[key] = {"ms_per_step": dt * 1e3, "frac": nbm / dt / (HBM_PEAK_GBPS * 1e9), "algorithmic_bytes": nbm, "qp_map": memo,
+                       "bit_exact_vs_oracle": ok}
+            c3["bit_exact_vs_oracle"] &= ok
+            b.qp_map.free()
+            b.qp_map = None
+        c3["bit_exact_vs_oracle"] &= c3["luma_64x4k_lcg_bs_one_qp"]["bit_exact_vs_oracle"]
+        b.free()   # borrowed: the headline batch's src frames (read only here) stay where they are
+    out["config3_image2_bs_qpmap"] = c3
+    return out
+
+
+def smooth_qp_map(w, h, qp, ctu_log2=6):
+    """A QP per CTU as rate control leaves it: a slow ramp across the picture (+-3 around qp) with a small seeded wobble, so
+    that neighbouring CTUs mostly share a QP or differ by one."""
+    cw, ch = (w + (1 << ctu_log2) - 1) >> ctu_log2, (h + (1 << ctu_log2) - 1) >> ctu_log2
+    xx, yy = np.meshgrid(np.arange(cw), np.arange(ch))
+    rng = np.random.RandomState(41)
+    m = qp + 3.0 * np.sin(xx / max(cw, 1) * 3.1 + yy / max(ch, 1) * 1.7) + rng.randint(-1, 2, (ch, cw)) * (rng.rand(ch, cw) < 0.15)
+    return np.clip(np.rint(m), 0, 51).astype(np.uint8)
+
+
 def extra_h265_stages(ctx, args, frames, batch, steps, wall_settled):
     """The SAO pass alone (`sao_64`) and the spec-exact deblocking kernel (`h265_luma_64`: bS 2 on every interior edge) on 64
     frames of the luma batch; both stages are parity-unpinned (checked against this repository's own restatements)."""
@@ -605,6 +752,52 @@ def extra_h265_stages(ctx, args, frames, batch, steps, wall_settled):
     return out
 
 
+def e2e_legs(ctx, args, frames, barrier):
+    """The PCIe-inclusive rates of this rank (never `value`), each leg bracketed by the job's barrier so that with N ranks all N
+    host links and the shared host DRAM are busy at once:
+      host frame  hevc_deblocking_filter on ONE frame in ordinary pageable memory, a new buffer per call (what main.cu's
+                  ExecuteGpu does with the frame ReadYuvFrame hands it): median of 12 calls after 3 warm-up calls;
+      sequence    hevc_deblocking_filter_sequence on page-locked frames, three in flight (H2D || kernel || D2H)."""
+    from oracle import oracle
+    w, h, bd, qp = args.width, args.height, args.bit_depth, args.qp
+    sb = 1 if bd == 8 else 2
+    for _ in range(3):
+        yy = frames[0].copy()
+        ctx.filter_frame(yy, qp=qp, bit_depth=bd)
+    barrier()
+    ts, tms = [], []
+    for i in range(12):
+        yy = frames[i % len(frames)].copy()
+        a = time.perf_counter()
+        tm = ctx.filter_frame(yy, qp=qp, bit_depth=bd)
+        ts.append(time.perf_counter() - a)
+        tms.append(tm)
+    barrier()
+    ok_frame = bool(np.array_equal(yy, oracle.filter_plane(frames[11 % len(frames)], qp, bit_depth=bd, threads=8)))
+    med = float(np.median(ts))
+    out = {"frames_per_s": 1.0 / med, "wall_s": med, "wall_s_min": float(np.min(ts)), "host_threads": ctx.host_threads(),
+           "memory": "pageable, a new buffer per call", "host_frame_bit_exact": ok_frame}
+    for k in ("exec_s", "copy_s", "total_s", "pipelined_s"):
+        out[k] = float(np.median([t[k] for t in tms]))
+    out["strips"] = len(ctx.last_frame_trace())
+    ns = max(1, min(len(frames), args.e2e_frames))
+    pinned = [ctx.pinned_array((h, w), frames.dtype) for _ in range(ns)]
+    for i, p in enumerate(pinned):
+        p[:] = frames[i]
+    ctx.filter_sequence([(p,) for p in pinned[:4]], qp=qp, bit_depth=bd)  # warm-up (allocations)
+    for i, p in enumerate(pinned):
+        p[:] = frames[i]
+    barrier()
+    t_seq = ctx.filter_sequence([(p,) for p in pinned], qp=qp, bit_depth=bd)
+    barrier()
+    seq_ok = all(np.array_equal(pinned[i], oracle.filter_plane(frames[i], qp, bit_depth=bd, threads=8)) for i in (0, ns - 1))
+    out.update({"sequence_frames": ns, "sequence_s": t_seq, "sequence_frames_per_s": ns / t_seq,
+                "sequence_pcie_GBps": 2 * w * h * sb * ns / t_seq / 1e9, "sequence_bit_exact": bool(seq_ok)})
+    for p in pinned:
+        ctx.free_pinned(p)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -640,6 +833,9 @@ def main():
                     help="allow more ranks than HIP devices (ranks then share devices: rehearsal only, not a scaling figure)")
     ap.add_argument("--rank-timeout", type=float, default=540.0, help="seconds the self-spawned ranks of --gpus N may run")
     ap.add_argument("--no-telemetry", action="store_true", help="do not sample the card's clock / power files during the run")
+    ap.add_argument("--no-affinity", action="store_true",
+                    help="do not pin each rank to the CPUs next to its GPU (sysfs local_cpulist) before the first HIP call")
+    ap.add_argument("--e2e-frames", type=int, default=24, help="frames of the PCIe-inclusive streaming leg (every rank, between two barriers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs and the reference table line")
@@ -662,13 +858,33 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # Before the first HIP call of this process: run on the CPUs next to this rank's GPU (the runtime's helper threads inherit the
+    # mask, and the page-locked staging memory then lies in the DRAM the copies are made from).  The host is what the ranks of a
+    # node share; device = local_rank mod the GPUs the topology shows.
+    cpus = []
+    if not args.no_affinity:
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        n_topo = len(vis.split(",")) if vis else len(shard.gpu_pci_ids())
+        if n_topo:
+            cpus = shard.pin_to_gpu_cpus(local_rank % n_topo)
     dist = None
     if world > 1:
         import datetime
         import torch.distributed as dist  # gloo: control plane only, the data path has no collective
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.rank_timeout))
+        # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): stdout carries the ONE JSON line and nothing
+        # else, so the rendezvous runs with file descriptor 1 pointing at stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.rank_timeout))
+            dist.barrier()   # the first collective is what connects the pairs
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     w, h, F, bd = args.width, args.height, args.frames, args.bit_depth
     default_kernel = args.variant in ("auto", "packed") and args.diag is None and args.map == "auto"
@@ -701,7 +917,9 @@ def main():
         pci = ctx.pci_bus_id()
     except deblock.DeblockError:
         pci = None
-    frames = make_frames(w, h, F, bd, seed=1 + rank)
+    # ONE seeded frame set for the whole job, dealt f mod world: rank r owns the global frames r, r + world, ... (F of them)
+    gidx = shard.global_frames_of_rank(F, rank, world)
+    frames = make_frames(w, h, F * world, bd, seed=1, indices=gidx)
     batch = deblock.DeviceBatch(ctx, w, h, F, bit_depth=bd)
     batch.upload_all(frames)
     planes = batch.planes()
@@ -754,6 +972,29 @@ def main():
         want = frames[f] if args.variant == "copy" else oracle.filter_plane(frames[f], args.qp, bit_depth=bd, threads=8)
         bit_exact &= bool(np.array_equal(batch.download_frame(f), want))
 
+    # N-GPU output == 1-GPU output on a sample: every rank hashes 16 of its filtered frames; rank 0 filters two frames of every
+    # other rank's sample on ITS GPU again and compares (shard.frames_equal_across_ranks)
+    import hashlib
+    cross = None
+    if args.variant != "copy":
+        local_hashes = {gidx[f]: hashlib.sha256(batch.download_frame(f).tobytes()).hexdigest() for f in range(0, F, max(1, F // 16))}
+
+        def refilter(g):
+            one = deblock.DeviceBatch(ctx, w, h, 1, bit_depth=bd)
+            one.upload_all(make_frames(w, h, F * world, bd, seed=1, indices=[g]))
+            ctx.filter_device(one.planes(), args.qp, variant=variant)
+            ctx.synchronize()
+            sha = hashlib.sha256(one.download_frame(0).tobytes()).hexdigest()
+            one.free()
+            return sha
+        cross = shard.frames_equal_across_ranks(dist, rank, world, local_hashes, refilter)
+
+    # PCIe-inclusive legs, every rank at once between two barriers (never `value`): the reference-shaped host call on ONE pageable
+    # frame, and the streaming operator on page-locked frames
+    e2e = None
+    if not args.no_e2e and args.variant != "copy" and args.diag is None:
+        e2e = e2e_legs(ctx, args, frames, barrier)
+
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * F * args.steps / elapsed
     abytes = algorithmic_bytes_per_frame(w, h, sb) * F
@@ -778,7 +1019,13 @@ def main():
                               "uninterrupted stream); fewer than 5 samples => null; the power file is a slow average")
     per_rank = {"rank": rank, "device": device, "pci": pci, "frames_per_s": F * args.steps / my_elapsed,
                 "kernel_avg_ms": roof["kernel_avg_ms"], "kernel_ms_p50": roof["kernel_ms_p50"],
-                "engine_clock_MHz": roof["engine_clock_MHz"], "settle_ms": info["settle_ms"], "bit_exact_vs_oracle": bit_exact}
+                "engine_clock_MHz": roof["engine_clock_MHz"], "settle_ms": info["settle_ms"], "bit_exact_vs_oracle": bit_exact,
+                "cpus_pinned": len(cpus), "cpu_first": cpus[0] if cpus else None, "cpu_last": cpus[-1] if cpus else None,
+                "frames_first_global_index": gidx[0], "frames_global_stride": world}
+    if e2e:
+        per_rank.update({"e2e_host_frame_fps": e2e["frames_per_s"], "e2e_host_frame_s": e2e["wall_s"],
+                         "e2e_sequence_fps": e2e["sequence_frames_per_s"], "e2e_sequence_frames": e2e["sequence_frames"],
+                         "e2e_sequence_s": e2e["sequence_s"], "e2e_bit_exact": e2e["sequence_bit_exact"] and e2e["host_frame_bit_exact"]})
     ranks = shard.gather_objects(dist, per_rank)
     out = {
         "metric": "luma_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world,
@@ -793,38 +1040,17 @@ def main():
                    "oversubscribed": world > ndev,
                    "parallelism": "frame-parallel x%d, no collective" % world},
         "bit_exact_vs_oracle": bit_exact, "diagnostic_copy_only": args.variant == "copy",
-        "roofline": roof, "per_rank": ranks,
+        "roofline": roof, "per_rank": ranks, "cross_rank": cross,
     }
+    if e2e:
+        # the node's PCIe-inclusive figures: the units all ranks moved / the slowest rank's time, legs run between common barriers
+        out["e2e_host_frame"] = dict(e2e)
+        out["e2e_host_frame"]["all_ranks_sequence_frames_per_s"] = shard.aggregate_rate(ranks, "e2e_sequence_frames", "e2e_sequence_s")
+        out["e2e_host_frame"]["all_ranks_host_frames_per_s"] = (world / max(r["e2e_host_frame_s"] for r in ranks))
+        out["e2e_host_frame"]["all_ranks_sequence_pcie_GBps"] = (out["e2e_host_frame"]["all_ranks_sequence_frames_per_s"] * 2 * w * h * sb / 1e9)
     if rank == 0 and world == 1 and args.variant != "copy" and args.diag is None:
         if not args.no_extra:
             out["extra_configs"] = extra_configs(ctx, args, frames, batch, variant)
-        if not args.no_e2e:
-            # end-to-end (PCIe-inclusive) rate of the host-frame operator; never `value`
-            yy = frames[0].copy()
-            ctx.filter_frame(yy, qp=args.qp, bit_depth=bd)
-            ts = []
-            for _ in range(5):
-                yy = frames[0].copy()
-                a = time.perf_counter()
-                tm = ctx.filter_frame(yy, qp=args.qp, bit_depth=bd)
-                ts.append(time.perf_counter() - a)
-            out["e2e_host_frame"] = {"frames_per_s": 1.0 / float(np.median(ts)), "exec_s": tm["exec_s"],
-                                     "copy_s": tm["copy_s"], "total_s": tm["total_s"]}
-            # the streaming operator: 3 frames in flight (H2D || kernel || D2H), planes in page-locked memory
-            ns = min(F, 24)
-            pinned = [ctx.pinned_array((h, w), frames.dtype) for _ in range(ns)]
-            for i, p in enumerate(pinned):
-                p[:] = frames[i]
-            ctx.filter_sequence([(p,) for p in pinned[:4]], qp=args.qp, bit_depth=bd)  # warm-up (allocations)
-            for i, p in enumerate(pinned):
-                p[:] = frames[i]
-            t_seq = ctx.filter_sequence([(p,) for p in pinned], qp=args.qp, bit_depth=bd)
-            seq_ok = all(np.array_equal(pinned[i], oracle.filter_plane(frames[i], args.qp, bit_depth=bd, threads=8)) for i in (0, ns - 1))
-            out["e2e_host_frame"].update({"sequence_frames": ns, "sequence_frames_per_s": ns / t_seq,
-                                          "sequence_pcie_GBps": 2 * w * h * sb * ns / t_seq / 1e9,
-                                          "sequence_bit_exact": bool(seq_ok)})
-            for p in pinned:
-                ctx.free_pinned(p)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[: min(F, 8)], args.qp, bd, host_threads())
             if not args.no_extra and bd == 8:
@@ -837,6 +1063,10 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     extras_ok = all(v.get("bit_exact_vs_oracle", True) for v in out.get("extra_configs", {}).values())
+    if cross is not None and not cross["frames_equal_1gpu"]:
+        raise SystemExit("bench: frames filtered by other ranks differ from rank 0's GPU: %s" % cross["mismatches"])
+    if not all(r.get("e2e_bit_exact", True) for r in ranks):
+        raise SystemExit("bench: a PCIe-inclusive leg differs from the oracle")
     if not bit_exact or not extras_ok or not all(r.get("bit_exact_vs_oracle", True) for r in ranks):
         raise SystemExit("bench: HIP output differs from the oracle")
 

@@ -208,3 +208,50 @@ def pin_to_gpu_cpus(local_index, sysfs_root="/sys"):
         return []
     os.sched_setaffinity(0, pick)
     return sorted(pick)
+
+
+# ---- one seeded frame set over N ranks, and "N-GPU output == 1-GPU output"  ---------------------------
+
+def global_frames_of_rank(frames_per_rank, rank, world):
+    """Weak scaling on ONE frame set: the job's frames 0 .. frames_per_rank * world - 1 are dealt f mod world, so every rank
+    holds frames_per_rank of them and a 1-rank job holds exactly the frames rank 0 .. world-1 would share."""
+    return frames_of_rank(frames_per_rank * world, rank, world)
+
+
+def merge_frame_hashes(dist, local):
+    """{global frame index: sha256 hex} of the frames each rank hashed -> the union on every rank.  A frame reported by two
+    ranks is an error (the deal is a partition); frames nobody hashed are simply absent (ranks hash a sample)."""
+    merged = {}
+    for part in gather_objects(dist, dict(local)):
+        overlap = set(merged) & set(part)
+        if overlap:
+            raise RuntimeError("frames filtered by two ranks: %s" % sorted(overlap))
+        merged.update(part)
+    return merged
+
+
+def frames_equal_across_ranks(dist, rank, world, local_hashes, refilter, per_rank=2):
+    """Rank 0 filters `per_rank` of the frames every OTHER rank hashed on its own GPU again (refilter(global index) -> sha256
+    hex of the filtered frame) and compares: the N-GPU job's output equals what one GPU produces, frame by frame, on the
+    sample.  Returns the same dict on every rank: frames_hashed, frames_rechecked, frames_equal_1gpu, mismatches."""
+    merged = merge_frame_hashes(dist, local_hashes)
+    res = None
+    if rank == 0:
+        mism, n = [], 0
+        for r in range(1, world):
+            theirs = sorted(g for g in merged if owner_of_frame(g, world) == r)[:per_rank]
+            for g in theirs:
+                n += 1
+                if refilter(g) != merged[g]:
+                    mism.append(g)
+        res = {"frames_hashed": len(merged), "frames_rechecked_on_rank0": n, "frames_equal_1gpu": not mism, "mismatches": mism}
+    return gather_objects(dist, res)[0]
+
+
+def aggregate_rate(per_rank, units_key, seconds_key):
+    """Whole-job rate of a leg every rank ran between the same two barriers: the units all ranks processed / the slowest
+    rank's time (the contract's max-over-ranks)."""
+    secs = [r[seconds_key] for r in per_rank if r.get(seconds_key)]
+    if not secs:
+        return None
+    return sum(r[units_key] for r in per_rank if r.get(seconds_key)) / max(secs)

@@ -220,3 +220,106 @@ def test_bench_child_runner_kills_the_whole_process_group(tmp_path):
         raise AssertionError("grandchild %d survived the timeout" % gpid)
     out, err, rc = bench.run_group([sys.executable, "-c", "print('ok')"], 30)
     assert rc == 0 and out.strip() == "ok"
+
+
+# ---- round 4: one seeded frame set over N ranks, cross-rank equality, per-rank PCIe-inclusive legs, CPU affinity ------------
+
+def _worker_cross(rank, world, port, F, corrupt, out_q):
+    """What bench.py does around its timed region, with the oracle standing in for each rank's GPU: frames of ONE seeded set
+    dealt f mod world, 16-sample hashes merged, rank 0 re-filters two frames of every other rank, per-rank e2e figures gathered
+    and turned into the whole-job rates."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import importlib.util
+    import torch.distributed as dist
+    from gpu_video_codec_amd import shard
+    from oracle import oracle
+    spec = importlib.util.spec_from_file_location("bench_x", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gidx = shard.global_frames_of_rank(F, rank, world)
+    frames = bench.make_frames(64, 48, F * world, 8, seed=1, indices=gidx)
+    local = {}
+    for f in range(0, F, max(1, F // 16)):
+        out = oracle.filter_plane(frames[f], 32)
+        if corrupt and rank == 1 and f == 0:
+            out = out.copy()
+            out[5, 5] ^= 1      # one wrong sample on rank 1's "GPU"
+        local[gidx[f]] = hashlib.sha256(out.tobytes()).hexdigest()
+
+    def refilter(g):
+        y = bench.make_frames(64, 48, F * world, 8, seed=1, indices=[g])[0]
+        return hashlib.sha256(oracle.filter_plane(y, 32).tobytes()).hexdigest()
+    cross = shard.frames_equal_across_ranks(dist, rank, world, local, refilter)
+    per_rank = shard.gather_objects(dist, {"rank": rank, "e2e_sequence_frames": 24, "e2e_sequence_s": 0.010 * (rank + 1),
+                                           "e2e_host_frame_s": 0.0004 * (rank + 1)})
+    total = shard.aggregate_rate(per_rank, "e2e_sequence_frames", "e2e_sequence_s")
+    dist.barrier()
+    dist.destroy_process_group()
+    out_q.put((rank, gidx, cross, total, frames[:2].tobytes()))
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_two_ranks_share_one_frame_set_and_rank0_rechecks_the_others(corrupt):
+    import importlib.util
+    import torch.multiprocessing as mp
+    spec = importlib.util.spec_from_file_location("bench_y", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    F, world = 6, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90) + (50 if corrupt else 0)
+    procs = [ctx.Process(target=_worker_cross, args=(r, world, port, F, corrupt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = bench.make_frames(64, 48, F * world, 8, seed=1)       # what ONE rank of a 12-frame job holds
+    for rank, gidx, cross, total, first_two in res:
+        assert gidx == list(range(rank, F * world, world))
+        assert first_two == whole[gidx[:2]].tobytes()               # the same frames, wherever they are filtered
+        assert cross["frames_hashed"] == 2 * F and cross["frames_rechecked_on_rank0"] == 2
+        assert cross["frames_equal_1gpu"] == (not corrupt)
+        assert cross["mismatches"] == ([1] if corrupt else [])      # global frame 1 = rank 1's first frame
+        assert total == pytest.approx(48 / 0.020)                   # all ranks' frames / the slowest rank's time
+
+
+def test_gpu_cpu_topology_from_sysfs(tmp_path, monkeypatch):
+    """shard.cpus_near_gpu / pin_to_gpu_cpus read the KFD topology and the PCI function's local_cpulist -- no HIP call, so a
+    rank can pin itself before it initialises the runtime.  A fake sysfs tree: two CPU nodes, two GPUs on different sockets."""
+    from gpu_video_codec_amd import shard
+    nodes = tmp_path / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    props = {0: "cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n",
+             1: "cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n",
+             2: "cpu_cores_count 0\nsimd_count 1024\nlocation_id 8960\ndomain 0\n",      # 0x2300 -> 0000:23:00.0
+             3: "cpu_cores_count 0\nsimd_count 1024\nlocation_id 49408\ndomain 1\n"}     # 0xc100 -> 0001:c1:00.0
+    for n, text in props.items():
+        (nodes / str(n)).mkdir(parents=True)
+        (nodes / str(n) / "properties").write_text(text)
+    for pci, cpus in (("0000:23:00.0", "0-3,128-131\n"), ("0001:c1:00.0", "64-67\n")):
+        d = tmp_path / "bus" / "pci" / "devices" / pci
+        d.mkdir(parents=True)
+        (d / "local_cpulist").write_text(cpus)
+    root = str(tmp_path)
+    assert shard.gpu_pci_ids(root) == ["0000:23:00.0", "0001:c1:00.0"]
+    assert shard.parse_cpulist("0-2,7,9-10") == {0, 1, 2, 7, 9, 10} and shard.parse_cpulist("\n") == set()
+    assert shard.cpus_near_gpu(0, root, env={}) == {0, 1, 2, 3, 128, 129, 130, 131}
+    assert shard.cpus_near_gpu(1, root, env={}) == {64, 65, 66, 67}
+    assert shard.cpus_near_gpu(0, root, env={"HIP_VISIBLE_DEVICES": "1"}) == {64, 65, 66, 67}    # device 0 of the process = GPU 1
+    assert shard.cpus_near_gpu(2, root, env={}) == set()
+    assert shard.cpus_near_gpu(0, root, env={"HIP_VISIBLE_DEVICES": "GPU-abc"}) == set()          # UUID lists are left alone
+    assert shard.cpus_near_gpu(0, str(tmp_path / "nothing"), env={}) == set()
+    # pinning: intersected with what the process may use; nothing to intersect -> nothing changed
+    before = os.sched_getaffinity(0)
+    try:
+        applied = shard.pin_to_gpu_cpus(0, root)
+        assert applied == sorted(before & {0, 1, 2, 3, 128, 129, 130, 131})
+        assert os.sched_getaffinity(0) == (set(applied) if applied else before)
+    finally:
+        os.sched_setaffinity(0, before)
+    assert shard.pin_to_gpu_cpus(0, str(tmp_path / "nothing")) == []
