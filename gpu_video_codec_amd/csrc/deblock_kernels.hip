@@ -282,6 +282,36 @@ __device__ __forceinline__ dbk::BlockQp block_qp(const DbkArgs &a, int f, int by
     return q;
 }
 
+/* QP-map launches, luma (round 4): the segments' QPs as INDICES into the workgroup's operand table instead of tc / beta values
+ * (reference-exact mode: one index serves both halves of the table) */
+template <bool CHROMA>
+__device__ __forceinline__ dbk::QsTable block_qp_tab(const DbkArgs &a, int f, int by, int bx, const DBK_LDS uint32_t *tab)
+{
+    const uint8_t *map = a.qp_map + (long long)f * a.map_frame_stride;
+    const int sc = CHROMA ? 2 : 1, lw = a.plane_w * sc, lh = a.plane_h * sc;
+    int u[4];
+    dbk::block_unit_qps(map, a.map_stride, a.ctu_log2, sc, lw, lh, bx * 8 - 4, by * 8 - 4, u);
+    dbk::QsTable q;
+    q.tab = tab;
+    q.ib[0] = q.it[0] = dbk::seg_qp_avg(u[0], u[1]);
+    q.ib[1] = q.it[1] = dbk::seg_qp_avg(u[2], u[3]);
+    q.ib[2] = q.it[2] = dbk::seg_qp_avg(u[0], u[2]);
+    q.ib[3] = q.it[3] = dbk::seg_qp_avg(u[1], u[2]); /* hor2 pairs above-right with below-LEFT (cpu.h:383-414) */
+    return q;
+}
+
+/* The operand table of a reference-exact QP-map luma launch (deblock_packed.h, ktab_build): every lane of the workgroup fills
+ * its share of the 54 rows from the launch's tc / beta tables, one barrier, and the table is there for all waves.  Called at
+ * the very top of a kernel, before any wave can leave. */
+__device__ __forceinline__ const DBK_LDS uint32_t *ktab_setup(uint32_t *lds, const DbkArgs &a)
+{
+    dbk::ktab_build<false>(lds, (int)threadIdx.x, (int)blockDim.x,
+                           [&](int i) { return i < 52 ? (int)a.beta_tab[i] << a.shift : 0; },
+                           [&](int i) { return i < 52 ? (int)a.tc_tab[i] << a.shift : 0; });
+    __syncthreads();
+    return (const DBK_LDS uint32_t *)lds;
+}
+
 /*
  * Body of the packed kernel for one lane (= one offset block).
  *
@@ -296,8 +326,16 @@ __device__ __forceinline__ dbk::BlockQp block_qp(const DbkArgs &a, int f, int by
  */
 template <bool CHROMA, int MODE, bool NT, int PATH, bool QPMAP>
 __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int bx, bool active, int by0,
-                                            const DbkH265Args *hx = nullptr) /* hx: MODE 2 only */
+                                            const DbkH265Args *hx = nullptr /* MODE 2 only */,
+                                            uint32_t *ktab_lds = nullptr /* QPMAP luma: LDS for the workgroup's operand table */)
 {
+    /* QP-map luma launches: every wave of the workgroup passes ktab_setup() exactly once -- AFTER its row, bS and map loads have
+     * been issued, so that the table's construction (the first 54 lanes of the workgroup; the others wait at the barrier)
+     * overlaps the latency of loads the wave has to wait for anyway.  PATH 3 lets idle lanes leave first thing, and a lane that
+     * has left builds no row: there the table comes first. */
+    constexpr bool KT = QPMAP && !CHROMA && (MODE == 0 || MODE == 3);
+    const DBK_LDS uint32_t *ktab = nullptr;
+    if constexpr (KT && PATH == 3) ktab = ktab_setup(ktab_lds, a);
     /* PATH 0: interior wave, by == by0 wave-uniform, every lane owns both halves of all 8 rows.
      * PATH 1: every lane's 8 rows are inside the image, but lanes may sit in different block rows (row-major
      *         map) and the wave may hold frame-edge blocks (bx == 0 / nbx-1) or idle lanes: still ONE 8-byte
@@ -419,6 +457,15 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
 
     if constexpr (MODE == 0 || MODE == 3) { /* 3 = the filter with the timing-only ablation switches compiled in */
         const dbk::BlockBs bs = PATH == 3 ? load_bs_buffer_rowedge(a, f, by, bx) : load_bs_buffer<(PATH != 0)>(a, f, by, bx, active);
+        if constexpr (QPMAP && !CHROMA) {
+            dbk::QsTable qs = block_qp_tab<CHROMA>(a, f, by, active ? bx : 0, ktab);
+            if constexpr (PATH != 3) qs.tab = ktab_setup(ktab_lds, a);
+#ifdef HEVCDBK_DIAG
+            dbk::packed_filter_luma_block_src(L, R, bs, qs, MODE == 3 ? a.diag_ablate : 0);
+#else
+            dbk::packed_filter_luma_block_src(L, R, bs, qs);
+#endif
+        } else {
         const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
 #ifdef HEVCDBK_DIAG
         if constexpr (MODE == 3) {
@@ -434,6 +481,7 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
 #else
         dbk::packed_filter_block<CHROMA, !QPMAP>(L, R, bs, q);
 #endif
+        }
     }
 #ifdef HEVCDBK_DIAG
     else if constexpr (MODE == 1) {
@@ -547,7 +595,8 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
  */
 template <int MODE, bool NT, bool EDGE, bool QPMAP, bool CHROMA = false, bool WIDE = false>
 __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, int bx, bool active,
-                                              const DbkH265Args *hx = nullptr) /* hx: MODE 2 (spec-exact) only */
+                                              const DbkH265Args *hx = nullptr /* MODE 2 (spec-exact) only */,
+                                              const DBK_LDS uint32_t *ktab = nullptr /* QPMAP luma: the workgroup's operand table */)
 {
     const bool lv = active && bx > 0;
     const bool rv = active && bx < a.nbx - 1;
@@ -587,9 +636,13 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
 
     if constexpr (MODE == 0) {
         const dbk::BlockBs bs = load_bs_buffer<EDGE>(a, f, by, bx, active);
-        const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
-        if constexpr (CHROMA) dbk::packed_filter_chroma_block16(W, bs, q, a.max_v);
-        else dbk::packed_filter_luma_block16<WIDE, !QPMAP>(W, bs, q, a.max_v);
+        if constexpr (QPMAP && !CHROMA) {
+            dbk::packed_filter_luma_block16_src<WIDE>(W, bs, block_qp_tab<false>(a, f, by, active ? bx : 0, ktab), a.max_v);
+        } else {
+            const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
+            if constexpr (CHROMA) dbk::packed_filter_chroma_block16(W, bs, q, a.max_v);
+            else dbk::packed_filter_luma_block16<WIDE, !QPMAP>(W, bs, q, a.max_v);
+        }
     } else if constexpr (MODE == 2) { /* spec-exact mode, H.265 8.7.2 */
         int entry[4];
         load_bs_buffer_h265<EDGE ? 2 : 0>(a, f, by, bx, active, entry);
@@ -706,10 +759,15 @@ __device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
 template <int MODE, bool NT, bool LINEAR, bool QPMAP, bool WIDE = false>
 __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
 {
+    const DBK_LDS uint32_t *kt = nullptr;
+    if constexpr (QPMAP && MODE == 0) {
+        __shared__ uint32_t ktab[dbk::kKTabDwords];
+        kt = ktab_setup(ktab, a);
+    }
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
-    if (c.interior) packed16_body<MODE, NT, false, QPMAP, false, WIDE>(a, c.by, c.f, c.bx, true);
-    else packed16_body<MODE, NT, true, QPMAP, false, WIDE>(a, c.by, c.f, c.bx, c.active);
+    if (c.interior) packed16_body<MODE, NT, false, QPMAP, false, WIDE>(a, c.by, c.f, c.bx, true, nullptr, kt);
+    else packed16_body<MODE, NT, true, QPMAP, false, WIDE>(a, c.by, c.f, c.bx, c.active, nullptr, kt);
 }
 
 /* 16-bit containers: reference-exact chroma, and the spec-exact mode's luma / chroma (deblock_packed16.h) */
@@ -741,13 +799,18 @@ __global__ __launch_bounds__(1024) void dbk_packed16_h265_kernel(const DbkH265Ar
  * write-back.
  */
 template <bool CHROMA, int MODE, bool NT, bool LINEAR, bool QPMAP>
-__global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(QPMAP && !CHROMA ? 8 : 1, 8))) void dbk_packed_kernel(const DbkArgs a)
 {
+    uint32_t *kt = nullptr;
+    if constexpr (QPMAP && !CHROMA && (MODE == 0 || MODE == 3)) {
+        __shared__ uint32_t ktab[dbk::kKTabDwords];
+        kt = ktab;
+    }
     WaveCoords c;
-    if (!wave_coords<LINEAR>(a, c)) return;
-    if (c.interior) packed_body<CHROMA, MODE, NT, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0);
-    else if (c.rows_in) packed_body<CHROMA, MODE, NT, LINEAR ? 1 : 3, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0);
-    else packed_body<CHROMA, MODE, NT, 2, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0);
+    if (!wave_coords<LINEAR>(a, c)) return; /* a padding workgroup: all of its waves leave here */
+    if (c.interior) packed_body<CHROMA, MODE, NT, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0, nullptr, kt);
+    else if (c.rows_in) packed_body<CHROMA, MODE, NT, LINEAR ? 1 : 3, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, nullptr, kt);
+    else packed_body<CHROMA, MODE, NT, 2, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, nullptr, kt);
 }
 
 /* spec-exact mode (H.265 8.7.2), 8-bit samples, packed-int16 arithmetic: same mapping and memory path */

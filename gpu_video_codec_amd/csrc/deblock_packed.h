@@ -31,8 +31,10 @@ typedef short pk __attribute__((vector_size(4))); /* two int16 lanes in one VGPR
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DBK_DEV 1
+#define DBK_LDS __attribute__((address_space(3))) /* a pointer into the workgroup's LDS (ds_read, not flat) */
 #else
 #define DBK_DEV 0
+#define DBK_LDS
 #endif
 
 DBK_HD uint32_t pk_bits(pk a) { return __builtin_bit_cast(uint32_t, a); }
@@ -295,7 +297,101 @@ struct LumaKEager {
     DBK_HD uint32_t nP() const { return nP_; }
     DBK_HD uint32_t nmask() const { return nmask_; }
     DBK_HD bool tc_zero() const { return tc_zero_; }
+    /* the same operand set from the workgroup's table (below): ib = row of the beta-dependent operands, it = row of the
+     * tc-dependent ones -- four 16-byte LDS reads and no arithmetic where make() spends about 45 VALU instructions */
+    DBK_HD static LumaKEager load(const DBK_LDS uint32_t *tab, int ib, int it);
 };
+
+/*
+ * Round 4: the per-lane operand set of a QP-map launch comes out of a TABLE.  Every operand is a function of beta alone or of
+ * tc alone, beta and tc are table values of a QP index, so a launch has at most 52 (reference tables) / 54 (H.265 Table 8-12)
+ * different operand rows of each kind.  A workgroup computes all of them once, in LDS, with its first 54 lanes (ktab_build:
+ * about 60 instructions of one wave, then one barrier), and a segment's operands are then FOUR ds_read_b128 by the lane's
+ * two indices -- the LDS pipe is otherwise idle in these kernels -- instead of LumaKEager::make per segment (4 x ~45 of the
+ * 1043 VALU instructions per wave that made the QP-map kernels arithmetic-bound).  The eight per-lane byte loads
+ * of tc_tab / beta_tab from the kernel arguments go away with it.
+ *   rows 0 .. kKTabRows-1 of kKTabBetaDw dwords: filter_thr, km_dpq, km_e, side_thr
+ *   then rows of kKTabTcDw dwords:               kf, snegc, sc2, sk | nP, nmask, nc, nnegc | nc2, nnegc2, nlim, (unused)
+ *                                                (the decision's / strong filter's / normal filter's operands side by side)
+ */
+constexpr int kKTabRows = 54, kKTabBetaDw = 4, kKTabTcDw = 12;
+constexpr int kKTabTcBase = kKTabRows * kKTabBetaDw;
+constexpr int kKTabDwords = kKTabRows * (kKTabBetaDw + kKTabTcDw); /* 864 dwords = 3456 bytes */
+
+template <bool H265>
+DBK_HD void ktab_fill_beta(uint32_t *o, int beta)
+{
+    const LumaKLazy<H265> z{beta, 0};
+    o[0] = z.filter_thr(); o[1] = z.km_dpq(); o[2] = z.km_e(); o[3] = z.side_thr();
+}
+template <bool H265>
+DBK_HD void ktab_fill_tc(uint32_t *o, int tc)
+{
+    const LumaKLazy<H265> z{0, tc};
+    o[0] = z.kf(); o[1] = z.snegc(); o[2] = pk_bits(z.sc2()); o[3] = pk_bits(z.sk());
+    o[4] = z.nP(); o[5] = z.nmask(); o[6] = pk_bits(z.nc()); o[7] = pk_bits(z.nnegc());
+    o[8] = pk_bits(z.nc2()); o[9] = pk_bits(z.nnegc2()); o[10] = pk_bits(z.nlim()); o[11] = 0u;
+}
+/* thread `tid` of `nthreads` fills its share of the rows: beta_of(i) / tc_of(i) = the (bit-depth scaled) table values of index i */
+template <bool H265, class FB, class FT>
+DBK_HD void ktab_build(uint32_t *tab, int tid, int nthreads, FB beta_of, FT tc_of)
+{
+    for (int i = tid; i < kKTabRows; i += nthreads) {
+        ktab_fill_beta<H265>(tab + i * kKTabBetaDw, beta_of(i));
+        ktab_fill_tc<H265>(tab + kKTabTcBase + i * kKTabTcDw, tc_of(i));
+    }
+}
+
+/* The operand set of a segment as two row pointers into the table: every operand is read where it is used, so the decision's
+ * five operands, the strong filter's three and the normal filter's seven are never all live at once (15 VGPRs when loaded up
+ * front: 71 registers and 7 waves per SIMD for the QP-map kernel, against 8 waves with the reads placed by use); the compiler
+ * merges neighbouring reads of one basic block into ds_read_b64 / b128. */
+struct LumaKLds {
+    const DBK_LDS uint32_t *b, *t; /* beta row, tc row */
+    DBK_HD uint32_t filter_thr() const { return b[0]; }
+    DBK_HD uint32_t km_dpq() const { return b[1]; }
+    DBK_HD uint32_t km_e() const { return b[2]; }
+    DBK_HD uint32_t side_thr() const { return b[3]; }
+    DBK_HD uint32_t kf() const { return t[0]; }
+    DBK_HD bool strong_possible() const { return true; } /* a zero threshold's bias says so by itself (LumaKEager::make) */
+    DBK_HD uint32_t snegc() const { return t[1]; }
+    DBK_HD pk sc2() const { return bits_pk(t[2]); }
+    DBK_HD pk sk() const { return bits_pk(t[3]); }
+    DBK_HD uint32_t nP() const { return t[4]; }
+    DBK_HD uint32_t nmask() const { return t[5]; }
+    DBK_HD pk nc() const { return bits_pk(t[6]); }
+    DBK_HD pk nnegc() const { return bits_pk(t[7]); }
+    DBK_HD pk nc2() const { return bits_pk(t[8]); }
+    DBK_HD pk nnegc2() const { return bits_pk(t[9]); }
+    DBK_HD pk nlim() const { return bits_pk(t[10]); }
+    DBK_HD bool tc_zero() const { return t[10] == 0u; } /* nlim = 10 * tc in both halves */
+    DBK_HD static LumaKLds rows(const DBK_LDS uint32_t *tab, int ib, int it)
+    {
+        return LumaKLds{tab + ib * kKTabBetaDw, tab + kKTabTcBase + it * kKTabTcDw};
+    }
+};
+
+DBK_HD LumaKEager LumaKEager::load(const DBK_LDS uint32_t *tab, int ib, int it)
+{
+    LumaKEager k;
+    const DBK_LDS uint32_t *br = tab + ib * kKTabBetaDw, *tr = tab + kKTabTcBase + it * kKTabTcDw;
+#if DBK_DEV
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    const u4 b = *(const DBK_LDS u4 *)br, t0 = *(const DBK_LDS u4 *)tr, t1 = *(const DBK_LDS u4 *)(tr + 4);
+    const u3 t2 = *(const DBK_LDS u3 *)(tr + 8); /* 12 bytes: the row's last dword is padding, and a register not spent on it */
+#else
+    struct { uint32_t x, y, z, w; } b{br[0], br[1], br[2], br[3]}, t0{tr[0], tr[1], tr[2], tr[3]}, t1{tr[4], tr[5], tr[6], tr[7]},
+        t2{tr[8], tr[9], tr[10], 0u};
+#endif
+    k.filter_thr_ = b.x; k.km_dpq_ = b.y; k.km_e_ = b.z; k.side_thr_ = b.w;
+    k.kf_ = t0.x; k.snegc_ = t0.y; k.sc2_ = bits_pk(t0.z); k.sk_ = bits_pk(t0.w);
+    k.nP_ = t1.x; k.nmask_ = t1.y; k.nc_ = bits_pk(t1.z); k.nnegc_ = bits_pk(t1.w);
+    k.nc2_ = bits_pk(t2.x); k.nnegc2_ = bits_pk(t2.y); k.nlim_ = bits_pk(t2.z);
+    k.tc_zero_ = t2.z == 0u; /* nlim = 10 * tc in both halves */
+    k.strong_possible_ = true; /* as in make(): a zero threshold's bias says so by itself */
+    return k;
+}
 
 /*
  * Round 3 form.  Everything carries a small constant so that no instruction exists only to add one:
@@ -614,14 +710,32 @@ DBK_HD void luma_seg(Taps &a, Taps &b, int beta, int tc, int max_v, int ablate)
     else luma_pairs<WIDE, false>(a, b, LumaKEager::make<false>(beta, tc), max_v, ablate);
 }
 
-/* UNI: one QP for the whole launch (q.beta[] / q.tc[] hold four copies of two scalars), the segment constants are
- * wave-uniform and live in SGPRs; otherwise (per-CTU QP map) they are per-lane values */
-template <bool WIDE = false, bool UNI = true>
-DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const BlockBs &bs, const BlockQp &q,
-                            int max_v, Taps &ha, Taps &hb, Taps &ga, Taps &gb, int ablate = 0)
+/* Where the operands of segment s of a block come from:
+ *   QsValues<UNI>  beta / tc values.  UNI: one QP for the whole launch (q.beta[] / q.tc[] hold four copies of two scalars), the
+ *                  segment constants are wave-uniform and live in SGPRs; otherwise per-lane values, built per segment;
+ *   QsTable        per-lane INDICES into the workgroup's operand table (ktab_build): QP-map launches, round 4. */
+template <bool UNI>
+struct QsValues {
+    const BlockQp &q;
+    template <bool WIDE>
+    DBK_HD void seg(int s, Taps &a, Taps &b, int max_v, int ablate) const { luma_seg<WIDE, UNI>(a, b, q.beta[s], q.tc[s], max_v, ablate); }
+};
+struct QsTable {
+    const DBK_LDS uint32_t *tab;
+    int ib[4], it[4];
+    template <bool WIDE>
+    DBK_HD void seg(int s, Taps &a, Taps &b, int max_v, int ablate) const
+    {
+        luma_pairs<WIDE, false>(a, b, LumaKLds::rows(tab, ib[s], it[s]), max_v, ablate);
+    }
+};
+
+template <bool WIDE, class QS>
+DBK_HD void luma_block_core_src(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const BlockBs &bs, const QS &q,
+                                int max_v, Taps &ha, Taps &hb, Taps &ga, Taps &gb, int ablate = 0)
 {
-    if (bs.ver1 > 0) luma_seg<WIDE, UNI>(va1, vb1, q.beta[0], q.tc[0], max_v, ablate); /* cpu.h:164 */
-    if (bs.ver2 > 0) luma_seg<WIDE, UNI>(va2, vb2, q.beta[1], q.tc[1], max_v, ablate); /* cpu.h:228 */
+    if (bs.ver1 > 0) q.template seg<WIDE>(0, va1, vb1, max_v, ablate); /* cpu.h:164 */
+    if (bs.ver2 > 0) q.template seg<WIDE>(1, va2, vb2, max_v, ablate); /* cpu.h:228 */
     diag_barriers(ablate);
 
     /* hor1: lines = cols 0..3, pair A = cols (0,3) = ver taps (p3,p0), pair B = cols (1,2) = (p2,p1);
@@ -634,7 +748,7 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
     ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1); /* row 5 */
     ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1); /* row 6 */
     ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1); /* row 7 */
-    if (bs.hor1 > 0) luma_seg<WIDE, UNI>(ha, hb, q.beta[2], q.tc[2], max_v, ablate); /* cpu.h:292 */
+    if (bs.hor1 > 0) q.template seg<WIDE>(2, ha, hb, max_v, ablate); /* cpu.h:292 */
     diag_barriers(ablate);
 
     /* hor2: P lines = cols 4..7 (ver taps q0..q3) of rows 3..0, pair A = cols (4,7), B = cols (5,6);
@@ -645,18 +759,24 @@ DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const Bl
     ga.p3 = pick_lo(va1.q0, va1.q3); gb.p3 = pick_lo(va1.q1, va1.q2); /* row 0 */
     ga.q0 = ha.q0; ga.q1 = ha.q1; ga.q2 = ha.q2; ga.q3 = ha.q3;
     gb.q0 = hb.q0; gb.q1 = hb.q1; gb.q2 = hb.q2; gb.q3 = hb.q3;
-    if (bs.hor2 > 0) luma_seg<WIDE, UNI>(ga, gb, q.beta[3], q.tc[3], max_v, ablate); /* cpu.h:373 */
+    if (bs.hor2 > 0) q.template seg<WIDE>(3, ga, gb, max_v, ablate); /* cpu.h:373 */
     diag_barriers(ablate);
+}
+template <bool WIDE = false, bool UNI = true>
+DBK_HD void luma_block_core(Taps &va1, Taps &vb1, Taps &va2, Taps &vb2, const BlockBs &bs, const BlockQp &q,
+                            int max_v, Taps &ha, Taps &hb, Taps &ga, Taps &gb, int ablate = 0)
+{
+    luma_block_core_src<WIDE>(va1, vb1, va2, vb2, bs, QsValues<UNI>{q}, max_v, ha, hb, ga, gb, ablate);
 }
 
 /* 8-bit samples: L[r] = cols 0..3, R[r] = cols 4..7 of row r as bytes */
-template <bool UNI = true>
-DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, const BlockQp &q, int ablate = 0)
+template <class QS>
+DBK_HD void packed_filter_luma_block_src(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, const QS &q, int ablate = 0)
 {
     Taps va1 = unpack_ver(L[0], L[3], R[0], R[3]), vb1 = unpack_ver(L[1], L[2], R[1], R[2]);
     Taps va2 = unpack_ver(L[4], L[7], R[4], R[7]), vb2 = unpack_ver(L[5], L[6], R[5], R[6]);
     Taps ha, hb, ga, gb;
-    luma_block_core<false, UNI>(va1, vb1, va2, vb2, bs, q, 255, ha, hb, ga, gb, ablate);
+    luma_block_core_src<false>(va1, vb1, va2, vb2, bs, q, 255, ha, hb, ga, gb, ablate);
 
     /* final pack, once per row dword */
     L[0] = row_of(ha.p3, hb.p3); L[1] = row_of(ha.p2, hb.p2); L[2] = row_of(ha.p1, hb.p1); L[3] = row_of(ha.p0, hb.p0);
@@ -674,6 +794,12 @@ DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const B
     }
 }
 
+template <bool UNI = true>
+DBK_HD void packed_filter_luma_block(uint32_t (&L)[8], uint32_t (&R)[8], const BlockBs &bs, const BlockQp &q, int ablate = 0)
+{
+    packed_filter_luma_block_src(L, R, bs, QsValues<UNI>{q}, ablate);
+}
+
 /* 16-bit containers (bit depth 8..16): W[r][j] = columns (2j, 2j+1) of row r as two uint16.
  * Same arithmetic; only the moves in and out of the pair registers differ (samples are already
  * 16 bit wide, so a move is "pick two halves" instead of "pick two bytes and zero-extend"). */
@@ -687,13 +813,13 @@ DBK_HD Taps unpack_ver16(const uint32_t (&a)[4], const uint32_t (&b)[4])
     return t;
 }
 
-template <bool WIDE = false, bool UNI = true>
-DBK_HD void packed_filter_luma_block16(uint32_t (&W)[8][4], const BlockBs &bs, const BlockQp &q, int max_v)
+template <bool WIDE, class QS>
+DBK_HD void packed_filter_luma_block16_src(uint32_t (&W)[8][4], const BlockBs &bs, const QS &q, int max_v)
 {
     Taps va1 = unpack_ver16(W[0], W[3]), vb1 = unpack_ver16(W[1], W[2]);
     Taps va2 = unpack_ver16(W[4], W[7]), vb2 = unpack_ver16(W[5], W[6]);
     Taps ha, hb, ga, gb;
-    luma_block_core<WIDE, UNI>(va1, vb1, va2, vb2, bs, q, max_v, ha, hb, ga, gb);
+    luma_block_core_src<WIDE>(va1, vb1, va2, vb2, bs, q, max_v, ha, hb, ga, gb);
 
     /* pair A = cols (0,3) / (4,7), pair B = cols (1,2) / (5,6):  (c0,c1) = (A.lo,B.lo), (c2,c3) = (B.hi,A.hi) */
 #define DBK_ROW16(r, A, B, j)                                 \
@@ -708,6 +834,12 @@ DBK_HD void packed_filter_luma_block16(uint32_t (&W)[8][4], const BlockBs &bs, c
     W[7][2] = pk_bits(pick_hi(va2.q0, va2.q1)); W[7][3] = pk_bits(pick_hi(va2.q2, va2.q3));
     W[5][2] = pk_bits(pick_lo(vb2.q0, vb2.q1)); W[5][3] = pk_bits(pick_lo(vb2.q2, vb2.q3));
     W[6][2] = pk_bits(pick_hi(vb2.q0, vb2.q1)); W[6][3] = pk_bits(pick_hi(vb2.q2, vb2.q3));
+}
+
+template <bool WIDE = false, bool UNI = true>
+DBK_HD void packed_filter_luma_block16(uint32_t (&W)[8][4], const BlockBs &bs, const BlockQp &q, int max_v)
+{
+    packed_filter_luma_block16_src<WIDE>(W, bs, QsValues<UNI>{q}, max_v);
 }
 
 /* ---- the whole block: ver1 -> ver2 -> hor1 -> hor2 --------------------------------------- */

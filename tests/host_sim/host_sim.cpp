@@ -47,12 +47,32 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
     const int nbx = w / 8 + 1, nby = h / 8 + 1;
     const int limit_bx = is_chroma ? 2 * w / 8 : nbx - 1, limit_by = is_chroma ? 2 * h / 8 : nby - 1;
     const int n_vert = (w / 8 + 1) * h / 8, n_hor = (h / 8 + 1) * w / 8;
+#if HAVE_PACKED
+    /* QP-map launches of the packed luma kernels take a segment's operands from the workgroup's table (deblock_packed.h,
+     * ktab_build), indexed by the segment's QP: built here the way ktab_setup of deblock_kernels.hip builds it */
+    uint32_t ktab[dbk::kKTabDwords];
+    if (map && packed && !is_chroma)
+        dbk::ktab_build<false>(ktab, 0, 1, [&](int i) { return i < 52 ? (int)beta_tab[i] << shift : 0; },
+                               [&](int i) { return i < 52 ? (int)tc_tab[i] << shift : 0; });
+#endif
     for (int by = 0; by < nby; by++)
         for (int bx = 0; bx < nbx; bx++) {
             int v[8][8];
             load_block(plane, pitch_s, w, h, bx, by, v);
             dbk::BlockBs bs = dbk::load_block_bs(vbs, hbs, bx, by, w / 8 + 1, w / 8, limit_bx, limit_by, n_vert, n_hor);
             dbk::BlockQp q;
+#if HAVE_PACKED
+            dbk::QsTable qt;
+            qt.tab = ktab;
+            if (map && packed && !is_chroma) { /* the kernels' four map units (block_unit_qps) and their pairing */
+                int u[4];
+                dbk::block_unit_qps(map, map_stride, ctu_log2, 1, w, h, bx * 8 - 4, by * 8 - 4, u);
+                qt.ib[0] = qt.it[0] = dbk::seg_qp_avg(u[0], u[1]);
+                qt.ib[1] = qt.it[1] = dbk::seg_qp_avg(u[2], u[3]);
+                qt.ib[2] = qt.it[2] = dbk::seg_qp_avg(u[0], u[2]);
+                qt.ib[3] = qt.it[3] = dbk::seg_qp_avg(u[1], u[2]);
+            }
+#endif
             if (map) {
                 const int sc = is_chroma ? 2 : 1, lw = w * sc, lh = h * sc, x0 = bx * 8 - 4, y0 = by * 8 - 4;
                 const int qs[4] = {
@@ -72,10 +92,10 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
                     for (int j = 0; j < 4; j++) W[r][j] = (uint32_t)v[r][2 * j] | ((uint32_t)v[r][2 * j + 1] << 16);
                 /* UNI (second template argument) exactly as the kernels instantiate it: one QP => true, QP map => false */
                 if (max_v > 2047) { /* 12 bit: wide sums */
-                    if (map) dbk::packed_filter_luma_block16<true, false>(W, bs, q, max_v);
+                    if (map) dbk::packed_filter_luma_block16_src<true>(W, bs, qt, max_v);
                     else dbk::packed_filter_luma_block16<true, true>(W, bs, q, max_v);
                 } else {
-                    if (map) dbk::packed_filter_luma_block16<false, false>(W, bs, q, max_v);
+                    if (map) dbk::packed_filter_luma_block16_src<false>(W, bs, qt, max_v);
                     else dbk::packed_filter_luma_block16<false, true>(W, bs, q, max_v);
                 }
                 for (int r = 0; r < 8; r++)
@@ -106,7 +126,7 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
                     R[r] = (uint32_t)v[r][4] | ((uint32_t)v[r][5] << 8) | ((uint32_t)v[r][6] << 16) | ((uint32_t)v[r][7] << 24);
                 }
                 if (is_chroma) dbk::packed_filter_block<true>(L, R, bs, q);
-                else if (map) dbk::packed_filter_block<false, false>(L, R, bs, q);
+                else if (map) dbk::packed_filter_luma_block_src(L, R, bs, qt);
                 else dbk::packed_filter_block<false, true>(L, R, bs, q);
                 for (int r = 0; r < 8; r++)
                     for (int c = 0; c < 4; c++) {

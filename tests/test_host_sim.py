@@ -172,6 +172,15 @@ def test_packed_with_ctu_qp_map(sim, oracle):
         y10 = synth.blocky_plane(768, 576, seed=7, bit_depth=10)
         assert np.array_equal(run_sim(sim, oracle, y10, 0, qp_map=qmap, bit_depth=10, packed=1),
                               oracle.filter_plane(y10, 0, qp_map=qmap, bit_depth=10)), (lo, hi)
+        # round 4: the operands come out of the per-QP table (deblock_packed.h ktab_build / LumaKEager::load) -- 12 bit takes the
+        # WIDE sums through the same rows, and caller tables with large entries fill rows the default tables never reach
+        y12 = synth.blocky_plane(768, 576, seed=9, bit_depth=12)
+        assert np.array_equal(run_sim(sim, oracle, y12, 0, qp_map=qmap, bit_depth=12, packed=1),
+                              oracle.filter_plane(y12, 0, qp_map=qmap, bit_depth=12)), (lo, hi)
+        tct = (np.arange(52) * 3 % 97 + (np.arange(52) > 40) * 30).astype(np.uint8)
+        bt = (np.arange(52) * 5 % 200).astype(np.uint8)
+        assert np.array_equal(run_sim(sim, oracle, y, 0, qp_map=qmap, vbs=vb, hbs=hb, packed=1, tc_table=tct, beta_table=bt),
+                              oracle.filter_plane(y, 0, qp_map=qmap, vert_bs=vb, hor_bs=hb, tc_table=tct, beta_table=bt)), (lo, hi)
 
 
 def test_packed_core_operand_range_with_maximal_custom_tables(sim, oracle):
