@@ -312,6 +312,16 @@ __device__ __forceinline__ const DBK_LDS uint32_t *ktab_setup(uint32_t *lds, con
     return (const DBK_LDS uint32_t *)lds;
 }
 
+/* the same for the spec-exact mode: rows by Table 8-12's two indices (beta: 0..51, tc: 0..53), the standard's thresholds */
+__device__ __forceinline__ const DBK_LDS uint32_t *ktab_setup_h265(uint32_t *lds, int shift)
+{
+    dbk::ktab_build<true>(lds, (int)threadIdx.x, (int)blockDim.x,
+                          [&](int i) { return dbk::h265_beta(i < 52 ? i : 51) << shift; },
+                          [&](int i) { return dbk::h265_tc(i) << shift; });
+    __syncthreads();
+    return (const DBK_LDS uint32_t *)lds;
+}
+
 /*
  * Body of the packed kernel for one lane (= one offset block).
  *
@@ -333,9 +343,9 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
      * been issued, so that the table's construction (the first 54 lanes of the workgroup; the others wait at the barrier)
      * overlaps the latency of loads the wave has to wait for anyway.  PATH 3 lets idle lanes leave first thing, and a lane that
      * has left builds no row: there the table comes first. */
-    constexpr bool KT = QPMAP && !CHROMA && (MODE == 0 || MODE == 3);
+    constexpr bool KT = QPMAP && !CHROMA && (MODE == 0 || MODE == 2 || MODE == 3);
     const DBK_LDS uint32_t *ktab = nullptr;
-    if constexpr (KT && PATH == 3) ktab = ktab_setup(ktab_lds, a);
+    if constexpr (KT && PATH == 3) ktab = MODE == 2 ? ktab_setup_h265(ktab_lds, 0) : ktab_setup(ktab_lds, a);
     /* PATH 0: interior wave, by == by0 wave-uniform, every lane owns both halves of all 8 rows.
      * PATH 1: every lane's 8 rows are inside the image, but lanes may sit in different block rows (row-major
      *         map) and the wave may hold frame-edge blocks (bx == 0 / nbx-1) or idle lanes: still ONE 8-byte
@@ -502,7 +512,12 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             dbk::h265_block_qpl4(a.qp_map + (long long)f * a.map_frame_stride, a.map_stride, a.ctu_log2, sc, a.plane_w * sc,
                                  a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, qpl);
             const dbk::H265Prm prm = {hx->tc_off, hx->beta_off, hx->c_qp_offset, 0, 255};
-            dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);
+            if constexpr (KT) {
+                if constexpr (PATH != 3) ktab = ktab_setup_h265(ktab_lds, 0);
+                dbk::h265_seg_rows(entry, qpl, prm, ktab, sg);
+            } else {
+                dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);
+            }
         } else { /* one QP: beta is a scalar and tc one of two scalars picked by the bS */
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -515,7 +530,7 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
             const dbk::H265Uni u = dbk::h265_uni(hx->beta_s, hx->tc_bs1, hx->tc_bs2);
             dbk::packed_filter_block_h265<CHROMA>(L, R, sg, &u);
         } else {
-            dbk::packed_filter_block_h265<CHROMA>(L, R, sg);
+            dbk::packed_filter_block_h265<CHROMA, KT>(L, R, sg);
         }
     }
 
@@ -596,8 +611,9 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
 template <int MODE, bool NT, bool EDGE, bool QPMAP, bool CHROMA = false, bool WIDE = false>
 __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, int bx, bool active,
                                               const DbkH265Args *hx = nullptr /* MODE 2 (spec-exact) only */,
-                                              const DBK_LDS uint32_t *ktab = nullptr /* QPMAP luma: the workgroup's operand table */)
+                                              uint32_t *ktab_lds = nullptr /* QPMAP luma: LDS for the workgroup's operand table */)
 {
+    constexpr bool KT = QPMAP && !CHROMA && (MODE == 0 || MODE == 2); /* packed_body: built after the loads have been issued */
     const bool lv = active && bx > 0;
     const bool rv = active && bx < a.nbx - 1;
     const int y0 = by * 8 - 4;
@@ -636,8 +652,10 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
 
     if constexpr (MODE == 0) {
         const dbk::BlockBs bs = load_bs_buffer<EDGE>(a, f, by, bx, active);
-        if constexpr (QPMAP && !CHROMA) {
-            dbk::packed_filter_luma_block16_src<WIDE>(W, bs, block_qp_tab<false>(a, f, by, active ? bx : 0, ktab), a.max_v);
+        if constexpr (KT) {
+            dbk::QsTable qs = block_qp_tab<false>(a, f, by, active ? bx : 0, nullptr);
+            qs.tab = ktab_setup(ktab_lds, a);
+            dbk::packed_filter_luma_block16_src<WIDE>(W, bs, qs, a.max_v);
         } else {
             const dbk::BlockQp q = block_qp<QPMAP, CHROMA>(a, f, by, active ? bx : 0);
             if constexpr (CHROMA) dbk::packed_filter_chroma_block16(W, bs, q, a.max_v);
@@ -653,7 +671,8 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
             dbk::h265_block_qpl4(a.qp_map + (long long)f * a.map_frame_stride, a.map_stride, a.ctu_log2, sc, a.plane_w * sc,
                                  a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, qpl);
             const dbk::H265Prm prm = {hx->tc_off, hx->beta_off, hx->c_qp_offset, a.shift, a.max_v};
-            dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);
+            if constexpr (KT) dbk::h265_seg_rows(entry, qpl, prm, ktab_setup_h265(ktab_lds, a.shift), sg);
+            else dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -666,7 +685,7 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
             const dbk::H265Uni u = dbk::h265_uni(hx->beta_s, hx->tc_bs1, hx->tc_bs2);
             dbk::packed_filter_block16_h265<CHROMA, WIDE>(W, sg, a.max_v, &u);
         } else {
-            dbk::packed_filter_block16_h265<CHROMA, WIDE>(W, sg, a.max_v);
+            dbk::packed_filter_block16_h265<CHROMA, WIDE, KT>(W, sg, a.max_v);
         }
     }
 
@@ -759,10 +778,10 @@ __device__ __forceinline__ bool wave_coords(const DbkArgs &a, WaveCoords &c)
 template <int MODE, bool NT, bool LINEAR, bool QPMAP, bool WIDE = false>
 __global__ __launch_bounds__(1024) void dbk_packed16_kernel(const DbkArgs a)
 {
-    const DBK_LDS uint32_t *kt = nullptr;
+    uint32_t *kt = nullptr;
     if constexpr (QPMAP && MODE == 0) {
         __shared__ uint32_t ktab[dbk::kKTabDwords];
-        kt = ktab_setup(ktab, a);
+        kt = ktab;
     }
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
@@ -783,10 +802,15 @@ template <bool CHROMA, bool LINEAR, bool QPMAP, bool WIDE = false>
 __global__ __launch_bounds__(1024) void dbk_packed16_h265_kernel(const DbkH265Args h)
 {
     const DbkArgs &a = h.base;
+    uint32_t *kt = nullptr;
+    if constexpr (QPMAP && !CHROMA) {
+        __shared__ uint32_t ktab[dbk::kKTabDwords];
+        kt = ktab;
+    }
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
-    if (c.interior) packed16_body<2, false, false, QPMAP, CHROMA, WIDE>(a, c.by, c.f, c.bx, true, &h);
-    else packed16_body<2, false, true, QPMAP, CHROMA, WIDE>(a, c.by, c.f, c.bx, c.active, &h);
+    if (c.interior) packed16_body<2, false, false, QPMAP, CHROMA, WIDE>(a, c.by, c.f, c.bx, true, &h, kt);
+    else packed16_body<2, false, true, QPMAP, CHROMA, WIDE>(a, c.by, c.f, c.bx, c.active, &h, kt);
 }
 
 /*
@@ -818,14 +842,19 @@ template <bool CHROMA, bool LINEAR, bool QPMAP>
 __device__ __forceinline__ void packed_h265_dispatch(const DbkH265Args &h)
 {
     const DbkArgs &a = h.base;
+    uint32_t *kt = nullptr;
+    if constexpr (QPMAP && !CHROMA) {
+        __shared__ uint32_t ktab[dbk::kKTabDwords];
+        kt = ktab;
+    }
     WaveCoords c;
     if (!wave_coords<LINEAR>(a, c)) return;
-    if (c.interior) packed_body<CHROMA, 2, false, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0, &h);
-    else if (c.rows_in) packed_body<CHROMA, 2, false, LINEAR ? 1 : 3, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
-    else packed_body<CHROMA, 2, false, 2, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, &h);
+    if (c.interior) packed_body<CHROMA, 2, false, 0, QPMAP>(a, c.by, c.f, c.bx, true, c.by0, &h, kt);
+    else if (c.rows_in) packed_body<CHROMA, 2, false, LINEAR ? 1 : 3, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, &h, kt);
+    else packed_body<CHROMA, 2, false, 2, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, &h, kt);
 }
 template <bool CHROMA, bool LINEAR, bool QPMAP>
-__global__ __launch_bounds__(1024) void dbk_packed_h265_kernel(const DbkH265Args h)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(QPMAP && !CHROMA ? 8 : 1, 8))) void dbk_packed_h265_kernel(const DbkH265Args h)
 {
     packed_h265_dispatch<CHROMA, LINEAR, QPMAP>(h);
 }

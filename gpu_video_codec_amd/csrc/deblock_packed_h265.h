@@ -160,6 +160,19 @@ DBK_HD void luma_pairs_h265_map(Taps &a, Taps &b, int entry, int beta, int tc, i
     if (any_lane(fast)) luma_pairs<WIDE, false>(a, b, LumaKEager::make<true>(beta, tc), max_v, 0, fast);
 }
 
+/* The same with the operands out of the workgroup's table (deblock_packed.h, ktab_build<true>: rows by the beta index
+ * qPL + beta_offset and the tc index qPL + 2 (bS - 1) + tc_offset, round 4): no beta / tc values are looked up at all unless
+ * a lane of the wave carries a keep flag. */
+template <bool WIDE = false>
+DBK_HD void luma_pairs_h265_tab(Taps &a, Taps &b, int entry, const DBK_LDS uint32_t *tab, int ib, int it, int shift, int max_v)
+{
+    const int bs = entry & kH265BsMask;
+    const bool keep = (entry & (kH265KeepP | kH265KeepQ)) != 0;
+    if (any_lane(bs != 0 && keep)) luma_pairs_h265<WIDE>(a, b, keep ? entry : 0, h265_beta(ib) << shift, h265_tc(it) << shift, max_v);
+    const bool fast = bs != 0 && !keep;
+    if (any_lane(fast)) luma_pairs<WIDE, false>(a, b, LumaKLds::rows(tab, ib, it), max_v, 0, fast);
+}
+
 /* one luma segment from its two pairs; entry = bS byte with the keep flags; beta / tc already looked up */
 template <bool WIDE>
 DBK_HD void luma_pairs_h265(Taps &a, Taps &b, int entry, int beta, int tc, int max_v)
@@ -194,22 +207,30 @@ DBK_HD void luma_pairs_h265(Taps &a, Taps &b, int entry, int beta, int tc, int m
 struct H265Seg {
     int entry[4]; /* bS bytes: ver1, ver2, hor1, hor2 */
     int tc[4], beta[4];
+    /* TAB form (QP-map luma launches): rows of the workgroup's operand table instead of the values above */
+    const DBK_LDS uint32_t *tab;
+    int ib[4], it[4], shift;
 };
-/* a segment of a one-QP kernel (u != NULL) or of a QP-map kernel */
-template <bool WIDE = false>
+/* a segment of a one-QP kernel (u != NULL) or of a QP-map kernel (TAB: operands from the workgroup's table) */
+template <bool WIDE = false, bool TAB = false>
 DBK_HD void luma_seg_h265(Taps &a, Taps &b, const H265Seg &s, int i, int max_v, const H265Uni *u)
 {
-    if (u) luma_pairs_h265_uni<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v, *u);
-    else luma_pairs_h265_map<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v);
+    if constexpr (TAB) {
+        luma_pairs_h265_tab<WIDE>(a, b, s.entry[i], s.tab, s.ib[i], s.it[i], s.shift, max_v);
+    } else {
+        if (u) luma_pairs_h265_uni<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v, *u);
+        else luma_pairs_h265_map<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v);
+    }
 }
 
 /* 8-bit luma block: ver1 -> ver2 -> hor1 -> hor2 with the conformant hor2 (P and Q both in columns 4..7) */
+template <bool TAB = false>
 DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], const H265Seg &s, const H265Uni *u = nullptr)
 {
     Taps va1 = unpack_ver(L[0], L[3], R[0], R[3]), vb1 = unpack_ver(L[1], L[2], R[1], R[2]);
     Taps va2 = unpack_ver(L[4], L[7], R[4], R[7]), vb2 = unpack_ver(L[5], L[6], R[5], R[6]);
-    luma_seg_h265(va1, vb1, s, 0, 255, u);
-    luma_seg_h265(va2, vb2, s, 1, 255, u);
+    luma_seg_h265<false, TAB>(va1, vb1, s, 0, 255, u);
+    luma_seg_h265<false, TAB>(va2, vb2, s, 1, 255, u);
 
     Taps ha, hb, ga, gb;
     /* hor1: lines = cols 0..3 (ver taps p3..p0), P_k = row 3-k, Q_k = row 4+k */
@@ -221,7 +242,7 @@ DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], co
     ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1);
     ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1);
     ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1);
-    luma_seg_h265(ha, hb, s, 2, 255, u);
+    luma_seg_h265<false, TAB>(ha, hb, s, 2, 255, u);
     /* hor2: lines = cols 4..7 (ver taps q0..q3), same rows */
     ga.p0 = pick_hi(va1.q0, va1.q3); gb.p0 = pick_hi(va1.q1, va1.q2);
     ga.p1 = pick_hi(vb1.q0, vb1.q3); gb.p1 = pick_hi(vb1.q1, vb1.q2);
@@ -231,7 +252,7 @@ DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], co
     ga.q1 = pick_lo(vb2.q0, vb2.q3); gb.q1 = pick_lo(vb2.q1, vb2.q2);
     ga.q2 = pick_hi(vb2.q0, vb2.q3); gb.q2 = pick_hi(vb2.q1, vb2.q2);
     ga.q3 = pick_hi(va2.q0, va2.q3); gb.q3 = pick_hi(va2.q1, va2.q2);
-    luma_seg_h265(ga, gb, s, 3, 255, u);
+    luma_seg_h265<false, TAB>(ga, gb, s, 3, 255, u);
 
     L[0] = row_of(ha.p3, hb.p3); L[1] = row_of(ha.p2, hb.p2); L[2] = row_of(ha.p1, hb.p1); L[3] = row_of(ha.p0, hb.p0);
     L[4] = row_of(ha.q0, hb.q0); L[5] = row_of(ha.q1, hb.q1); L[6] = row_of(ha.q2, hb.q2); L[7] = row_of(ha.q3, hb.q3);
@@ -281,7 +302,7 @@ DBK_HD void chroma_hor_h265(uint32_t (&X)[8], int tc, int entry)
     X[4] = perm(pk_bits(bq0), pk_bits(aq0), 0x02060400u);
 }
 
-template <bool CHROMA>
+template <bool CHROMA, bool TAB = false>
 DBK_HD void packed_filter_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], const H265Seg &s, const H265Uni *u = nullptr)
 {
     if constexpr (CHROMA) {
@@ -290,7 +311,7 @@ DBK_HD void packed_filter_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], const H
         chroma_hor_h265(L, s.tc[2], s.entry[2]);
         chroma_hor_h265(R, s.tc[3], s.entry[3]);
     } else {
-        packed_filter_luma_block_h265(L, R, s, u);
+        packed_filter_luma_block_h265<TAB>(L, R, s, u);
     }
 }
 
@@ -309,6 +330,22 @@ DBK_HD void h265_seg_params(const int (&entry)[4], const int (&qpl)[4], const H2
             s.beta[i] = h265_beta(clampi(qpl[i] + p.beta_off, 0, 51)) << p.shift;
             s.tc[i] = h265_tc(clampi(qpl[i] + 2 * (bs - 1) + p.tc_off, 0, 53)) << p.shift;
         }
+    }
+}
+
+/* TAB form, luma: the table rows of the four segments (nothing is looked up here) */
+DBK_HD void h265_seg_rows(const int (&entry)[4], const int (&qpl)[4], const H265Prm &p, const DBK_LDS uint32_t *tab, H265Seg &s)
+{
+    s.tab = tab;
+    s.shift = p.shift;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int bs = entry[i] & kH265BsMask;
+        s.entry[i] = entry[i];
+        s.ib[i] = clampi(qpl[i] + p.beta_off, 0, 51);
+        s.it[i] = clampi(qpl[i] + 2 * (bs - 1) + p.tc_off, 0, 53);
+        s.tc[i] = 0;
+        s.beta[i] = 0;
     }
 }
 

@@ -182,6 +182,12 @@ static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint
                                            dbk::h265_tc(dbk::clampi(qp + prm.tc_off, 0, 53)) << prm.shift,
                                            dbk::h265_tc(dbk::clampi(qp + 2 + prm.tc_off, 0, 53)) << prm.shift);
     const dbk::H265Uni *const u = (map || c_idx) ? nullptr : &uni;
+    /* QP-map luma launches of the packed kernels: operands from the workgroup's table, as ktab_setup_h265 builds it */
+    const bool tabbed = map && !c_idx;
+    uint32_t ktab[dbk::kKTabDwords];
+    if (tabbed)
+        dbk::ktab_build<true>(ktab, 0, 1, [&](int i) { return dbk::h265_beta(i < 52 ? i : 51) << prm.shift; },
+                              [&](int i) { return dbk::h265_tc(i) << prm.shift; });
 #endif
     for (int by = 0; by < nby; by++)
         for (int bx = 0; bx < nbx; bx++) {
@@ -196,7 +202,11 @@ static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint
                     for (int j = 0; j < 4; j++) W[r][j] = (uint32_t)v[r][2 * j] | ((uint32_t)v[r][2 * j + 1] << 16);
                 dbk::H265Seg sg;
                 if (c_idx) { dbk::h265_seg_params<true>(entry, qpl, prm, sg); dbk::packed_filter_block16_h265<true>(W, sg, prm.max_v); }
-                else {
+                else if (tabbed) {
+                    dbk::h265_seg_rows(entry, qpl, prm, ktab, sg);
+                    if (prm.max_v > 2047) dbk::packed_filter_block16_h265<false, true, true>(W, sg, prm.max_v);
+                    else dbk::packed_filter_block16_h265<false, false, true>(W, sg, prm.max_v);
+                } else {
                     dbk::h265_seg_params<false>(entry, qpl, prm, sg);
                     if (prm.max_v > 2047) dbk::packed_filter_block16_h265<false, true>(W, sg, prm.max_v, u);
                     else dbk::packed_filter_block16_h265<false>(W, sg, prm.max_v, u);
@@ -217,6 +227,7 @@ static void run_h265(T *plane, int w, int h, long pitch_s, int c_idx, const uint
                 }
                 dbk::H265Seg sg;
                 if (c_idx) { dbk::h265_seg_params<true>(entry, qpl, prm, sg); dbk::packed_filter_block_h265<true>(L, R, sg); }
+                else if (tabbed) { dbk::h265_seg_rows(entry, qpl, prm, ktab, sg); dbk::packed_filter_block_h265<false, true>(L, R, sg); }
                 else { dbk::h265_seg_params<false>(entry, qpl, prm, sg); dbk::packed_filter_block_h265<false>(L, R, sg, u); }
                 for (int r = 0; r < 8; r++)
                     for (int c = 0; c < 4; c++) {
