@@ -811,8 +811,12 @@ int hevcdbk_device_replay(hevcdbk_context *ctx, const hevcdbk_device_planes *pla
     r->settle_launches = 0; r->settle_ms = 0; r->settled = 0; r->settle_tail_mean_ms = 0;
     std::vector<float> hist; /* durations of completed settle launches, in launch order */
     unsigned launched = 0, read = 0;
-    const double t_first = monotonic_s();
     bool stop = !(r->settle_max_ms > 0);
+    /* with neither settling nor warm-up nothing precedes the timed launches inside this call, and the front bracket is the
+     * moment they are handed over: work an earlier asynchronous call left on the compute stream must not be inside the
+     * bracket, so the stream is drained first -- its queue is empty at t_first */
+    if (stop && warm == 0) HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
+    const double t_first = monotonic_s();
     auto harvest = [&](bool block) -> int {
         while (read < launched) {
             hipEvent_t e0 = ev[2 * (read % kRing)], e1 = ev[2 * (read % kRing) + 1];

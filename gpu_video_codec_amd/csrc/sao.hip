@@ -441,6 +441,18 @@ hipError_t dbk_launch_sao(const DbkSaoArgs &a, int sample_bytes, hipStream_t str
                           a.plane_w % 8 == 0 && a.plane_h % 8 == 0 && a.max_v == 255 && a.band_shift == 3 &&
                           (unsigned long long)a.pitch * (unsigned long long)a.plane_h < (1ull << 31); /* 32-bit buffer offsets */
     if (!(sample_bytes == 1 && aligned8)) waves = 4;
+#ifdef HEVCDBK_DIAG
+    /* the narrower strips of the wg_cap knob exist for the renumbered grid only (sao8_kernel<true, 1 | 2>): with the plain
+     * 3-D numbering -- the noswz knob, or a grid too large to renumber -- the launch below is sao8_kernel<false, 4>, whose
+     * strips are 256 samples wide, and block / grid must be sized for that (half or three quarters of each strip
+     * row stayed unwritten when both knobs were set) */
+    {
+        const unsigned long long tx0 = (unsigned long long)(a.plane_w + 64 * waves - 1) / (64 * waves), tpf0 = tx0 * ((a.plane_h + 63) / 64);
+        const unsigned long long tot0 = tpf0 * (unsigned long long)a.n_frames;
+        const bool swz0 = !g_dbk_diag.noswz && tot0 + 8 < (1ull << 31) && (tot0 + 8) * tpf0 < (1ull << 32) && tpf0 * tx0 < (1ull << 32);
+        if (!swz0) waves = 4;
+    }
+#endif
     const int strip_w = 64 * waves;
     const dim3 block(strip_w, 1, 1), grid3((a.plane_w + strip_w - 1) / strip_w, (a.plane_h + 63) / 64, a.n_frames);
     /* the renumbered 1-D grid (sao_strip): strips per frame and in total small enough for exact reciprocal division

@@ -353,12 +353,13 @@ class Context:
                                                ctb_log2, keep_ptr, keep_stride, keep_frame_stride, None), self.handle)
 
     def deblock_sao_device(self, planes, qp, params_ptr, params_stride, ctb_log2, *, params_frame_stride=0, keep_ptr=None,
-                           keep_stride=0, keep_frame_stride=0, tc_table=None, beta_table=None, fused=_lib.FUSED_AUTO):
-        """hevc_deblock_sao_device: reference-exact deblocking followed by SAO, src -> dst, one kernel where it applies."""
+                           keep_stride=0, keep_frame_stride=0, tc_table=None, beta_table=None, fused=_lib.FUSED_AUTO, stream=None):
+        """hevc_deblock_sao_device: reference-exact deblocking followed by SAO, src -> dst, one kernel where it applies.
+        stream: a hipStream_t handle of the caller (int), None = the context's compute stream."""
         t, _k = _tables(tc_table, beta_table)
         _chk(_lib.lib().hevc_deblock_sao_device(self.handle, C.byref(planes), int(qp), None if t is None else C.byref(t), params_ptr,
                                                 params_stride, params_frame_stride, ctb_log2, keep_ptr, keep_stride, keep_frame_stride,
-                                                fused, None), self.handle)
+                                                fused, stream), self.handle)
 
     def deblock_sao_h265_device(self, planes, qp, params_ptr, params_stride, ctb_log2, *, c_idx=0, tc_offset_div2=0,
                                 beta_offset_div2=0, cb_qp_offset=0, cr_qp_offset=0, params_frame_stride=0, keep_ptr=None,

@@ -255,7 +255,9 @@ HEVCDBK_API void *hevcdbk_compute_stream(hevcdbk_context *ctx); /* hipStream_t *
  * compute stream with a HIP event pair around EACH launch, synchronises once at the end and
  * writes the per-launch kernel durations (milliseconds) to kernel_ms[steps].  (= hevcdbk_device_replay with no
  * settling and no warm-up.)  The timing window is the reference's "execution time without copy": kernels + one
- * synchronisation, nothing else (gpu.cu:1266-1291). */
+ * synchronisation, nothing else (gpu.cu:1266-1291).  n_planes is 1 .. 3 (the planes of one 4:2:0 batch) and every plane
+ * holds the same n_frames -- anything else is HEVCDBK_ERR_ARG, here and in hevcdbk_device_replay; the compute stream is
+ * drained before the first launch, so work an earlier asynchronous call left on it is outside the window. */
 HEVCDBK_API int hevcdbk_device_run_timed(hevcdbk_context *ctx, const hevcdbk_device_planes *planes, unsigned n_planes,
                              unsigned qp, const hevcdbk_tables *tables, int kernel_variant,
                              unsigned steps, float *kernel_ms);

@@ -262,13 +262,41 @@ def test_reference_driver_links_against_the_library(tmp_path):
 
 def test_no_wide_store_is_overwritten_in_its_shadow():
     """Round 3 found a 16-byte buffer store whose data registers the very next VALU instruction overwrote (legal by the
-    compiler's hazard table when soffset is an SGPR; on MI355X the first launch of a process wrote garbage).  The scanner
-    compiles the product's three .hip files to ISA and looks for any 12- / 16-byte store followed within two issue slots by a
-    VALU write to its data registers."""
+    compiler's hazard table when soffset is an SGPR; on MI355X the first launch of a process wrote garbage;
+    profiles/r04/store_hazard.md).  tools/check_store_hazard.py scans the gfx950 code objects inside the SHIPPED libraries
+    (product and diagnostic) and the tools/ubench programs, following both sides of every branch; `make all` runs it too and
+    fails on a finding.  Its self-test (block-ending stores, branch targets, objdump and compiler listing forms) runs first."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_hazard.py")], capture_output=True, text=True, timeout=900)
+    tool = os.path.join(ROOT, "tools", "check_store_hazard.py")
+    r = subprocess.run([sys.executable, tool, "--self-test"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "self-test passed" in r.stdout, r.stdout
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert "0 suspicious" in r.stdout
+    assert "0 suspicious" in r.stdout and "libhevcdbk" not in r.stdout.replace("0 suspicious", "")
+    m = re.search(r"in (\d+) code object\(s\) of (\d+) file", r.stdout)
+    assert m and int(m.group(1)) >= 6 and int(m.group(2)) >= 2   # both libraries, three code objects each
+
+
+def test_toolchain_hazard_table_is_what_the_guard_assumes(tmp_path):
+    """tools/ubench/store_hazard_probe.hip, compile only: for a 16-byte buffer store whose data the next VALU instruction
+    overwrites, hipcc inserts two wait states on gfx950 when soffset is an immediate and NOTHING when it is an SGPR -- the
+    exempted form the kernels guard by hand with `s_nop 1`.  If a toolchain changes either fact, the guard's reasoning
+    (profiles/r04/store_hazard.md) needs another look."""
+    import subprocess
+    out = tmp_path / "probe.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-o", str(out),
+                           os.path.join(ROOT, "tools", "ubench", "store_hazard_probe.hip")], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+
+    def after_first_store(kernel):
+        body = text[text.index(kernel + ":"):]
+        lines = [l.strip() for l in body[:body.index("s_endpgm")].split("\n")]
+        i = next(k for k, l in enumerate(lines) if l.startswith("buffer_store_dwordx4"))
+        return lines[i], lines[i + 1]
+    st, nxt = after_first_store("_Z5k_immPhiPKj")
+    assert st.split(",")[-1].strip().startswith("0 ") and nxt == "s_nop 1", (st, nxt)
+    st, nxt = after_first_store("_Z6k_sgprPhiPKji")
+    assert re.search(r", s\d+ offen", st) and not nxt.startswith("s_nop"), (st, nxt)
 
 
 def test_staging_crew_on_cpu_plain_and_under_thread_sanitizer():

@@ -341,6 +341,62 @@ def test_deblock_sao_16bit_4k_repeated(ctx, h265, oracle):
     d.free()
 
 
+def test_two_launch_form_on_two_caller_streams(ctx, h265, oracle):
+    """the two-launch form of deblocking + SAO sends the deblocked planes through ONE scratch buffer per context while
+    the caller may hand in any stream; the buffer's reuse is fenced by an event (tmp_ev: the next user's stream waits for the
+    previous user's SAO launch) and it is only re-allocated after that event has completed.  Two caller streams, FUSED_OFF calls
+    on two different batches alternately with NO host synchronisation between them, then a larger batch (the scratch has to
+    grow while earlier work may still be queued) and the small ones again; every output against SAO(deblock(x)) of the oracles."""
+    import ctypes as C
+    from gpu_video_codec_amd import deblock, synth, _lib
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    streams = []
+    for _ in range(2):
+        s = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0   # hipStreamNonBlocking
+        streams.append(s)
+    qp = 34
+    cases = []
+    for i, (w, h, n) in enumerate(((640, 360 // 8 * 8, 3), (512, 384, 2), (1920, 1088, 4))):   # the third is the large one
+        fr = np.stack([synth.blocky_plane(w, h, seed=40 + 5 * i + f) for f in range(n)])
+        b = deblock.DeviceBatch(ctx, w, h, n, per_frame_bs=False)
+        b.upload_all(fr)
+        prm = h265.random_sao_params(w, h, 6, seed=7 + i)
+        d = ctx.alloc(prm.nbytes)
+        d.upload(prm.view(np.uint8).ravel())
+        want = [h265.sao_plane(oracle.filter_plane(fr[f], qp, threads=8), prm, 6) for f in range(n)]
+        cases.append((b, d, prm, want, n))
+    ctx.synchronize()   # the uploads are done; from here on nothing synchronises with the host until the end
+
+    def call(k, stream):
+        b, d, prm, _w, _n = cases[k]
+        ctx.deblock_sao_device(b.planes(), qp, d.ptr, prm.shape[1], 6, fused=_lib.FUSED_OFF, stream=stream)
+    try:
+        for rnd in range(6):
+            call(0, streams[0])
+            call(1, streams[1])
+        call(2, streams[0])          # scratch grows: the library waits for the event of the last small call first
+        for rnd in range(4):
+            call(1, streams[1])
+            call(0, streams[0])
+            call(2, streams[1])      # ... and the large one on the OTHER stream, fenced against its own previous use
+        for s in streams:
+            assert hip.hipStreamSynchronize(s) == 0
+        for k, (b, d, prm, want, n) in enumerate(cases):
+            for f in range(n):
+                assert np.array_equal(b.download_frame(f), want[f]), (k, f)
+    finally:
+        for s in streams:
+            hip.hipStreamSynchronize(s)
+            hip.hipStreamDestroy(s)
+        for b, d, _p, _w, _n in cases:
+            b.free()
+            d.free()
+
+
 def test_deblock_sao_yuv420_one_launch(ctx, h265, oracle):
     """hevc_deblock_sao_device_planes / hevc_deblock_sao_h265_device_planes: deblocking + SAO of Y, U and V of a 4:2:0
     batch in ONE call -- one fused launch whose grid holds the three planes' tiles one after the other (8 bit and 10 bit) --
