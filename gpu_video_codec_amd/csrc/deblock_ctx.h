@@ -66,5 +66,14 @@ int check_frame(const hevcdbk_frame &f, bool &chroma);
 int check_bs(const hevcdbk_bs *bs, unsigned W, unsigned H, bool chroma);
 int planes_to_args(const hevcdbk_device_planes *p, unsigned qp, const hevcdbk_tables *tables, DbkArgs &a);
 int launch(hevcdbk_context *ctx, const DbkArgs &a0, int sample_bytes, bool chroma, int variant, hipStream_t s);
+/* host side of the frame operators (deblock_host.cpp): the staging crew, and HBM the crew writes through the PCIe BAR */
+int ensure_crew(hevcdbk_context *ctx);
+/* fine-grained device memory of at least `bytes` that the host's cores can write (large-BAR devices), or NULL: no such memory here */
+uint8_t *push_buffer(hevcdbk_context *ctx, size_t bytes);
+/* every plane of `frame` (tight rows of pw[i] * sb bytes at base + plane_off[i]) copied by the crew and the calling thread, which
+ * returns when all of it is done.  to_frame: base -> the caller's planes, else the caller's planes -> base; base_is_device: base is
+ * HBM seen through the BAR (streaming stores, flushed by a read) */
+int crew_copy_frame(hevcdbk_context *ctx, const hevcdbk_frame *frame, int npl, const unsigned *pw, const unsigned *ph, unsigned sb,
+                    uint8_t *base, const size_t *plane_off, bool to_frame, bool base_is_device);
 
 } /* namespace dbkh */

@@ -437,6 +437,65 @@ int ensure_crew(hevcdbk_context *ctx)
     return HEVCDBK_OK;
 }
 
+uint8_t *push_buffer(hevcdbk_context *ctx, size_t bytes)
+{
+    if (ctx->large_bar < 0) {
+        int v = 0;
+        ctx->large_bar = hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, ctx->device) == hipSuccess && v ? 1 : 0;
+        (void)hipGetLastError();
+    }
+    if (ctx->large_bar != 1) return nullptr;
+    if (ctx->dev_push.cap < bytes) {
+        if (ctx->dev_push.p) (void)hipFree(ctx->dev_push.p);
+        ctx->dev_push.p = nullptr;
+        ctx->dev_push.cap = 0;
+        if (hipExtMallocWithFlags(&ctx->dev_push.p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->dev_push.p = nullptr;
+            return nullptr;
+        }
+        ctx->dev_push.cap = bytes;
+    }
+    return (uint8_t *)ctx->dev_push.p;
+}
+
+int crew_copy_frame(hevcdbk_context *ctx, const hevcdbk_frame *frame, int npl, const unsigned *pw, const unsigned *ph, unsigned sb,
+                    uint8_t *base, const size_t *plane_off, bool to_frame, bool base_is_device)
+{
+    size_t total = 0;
+    for (int i = 0; i < npl; i++) total += (size_t)pw[i] * ph[i] * sb;
+    /* below 1 MiB waking the crew costs more than it saves: the calling thread copies alone */
+    const bool threads = total >= ((size_t)1 << 20);
+    if (threads)
+        if (int rc = ensure_crew(ctx)) return rc;
+    StageCrew *crew = threads ? ctx->crew : nullptr;
+    const unsigned crew_n = crew && crew->workers() ? crew->workers() + 1 : 1;
+    CopyGroup g;
+    std::vector<CopyJob> jobs;
+    for (int i = 0; i < npl; i++) {
+        const size_t rb = (size_t)pw[i] * sb;
+        unsigned pieces = (unsigned)((rb * ph[i]) / ((size_t)256 << 10));
+        pieces = pieces < 1 ? 1 : pieces > 4 * crew_n ? 4 * crew_n : pieces;
+        for (unsigned p = 0; p < pieces; p++) {
+            const unsigned a = (unsigned)((uint64_t)ph[i] * p / pieces), b = (unsigned)((uint64_t)ph[i] * (p + 1) / pieces);
+            if (a == b) continue;
+            uint8_t *inner = base + plane_off[i] + (size_t)a * rb, *user = (uint8_t *)frame->plane[i] + (size_t)a * frame->pitch[i];
+            if (to_frame) jobs.push_back({user, inner, frame->pitch[i], rb, rb, b - a, &g, false});
+            else jobs.push_back({inner, user, rb, frame->pitch[i], rb, b - a, &g, base_is_device});
+        }
+    }
+    if (!crew) {
+        for (const CopyJob &j : jobs) copy_rows(j, true);
+        return HEVCDBK_OK;
+    }
+    g.pending.store((int)jobs.size(), std::memory_order_release);
+    crew->begin();
+    for (const CopyJob &j : jobs) crew->submit(j, to_frame ? StageCrew::LANE_OUT : StageCrew::LANE_IN);
+    crew->wait(g); /* this thread copies too */
+    crew->end();
+    return HEVCDBK_OK;
+}
+
 } /* namespace dbkh */
 
 using namespace dbkh;
@@ -1061,12 +1120,7 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
          * tools/ubench/bar_write.hip: 37-43 GB/s from one or two cores, as fast as filling the ring) -- no ring on the way in and no
          * H2D DMA with its set-up, event and cross-stream wait per strip.  The buffer is fine-grained device memory, so no cache of the
          * GPU holds a line of it across launches. */
-        if (ctx->large_bar < 0) {
-            int v = 0;
-            ctx->large_bar = hipDeviceGetAttribute(&v, hipDeviceAttributeIsLargeBar, ctx->device) == hipSuccess && v ? 1 : 0;
-            (void)hipGetLastError();
-        }
-        bool push_in = direct_out && ctx->large_bar == 1 && crew_knob("HEVCDBK_HOST_PUSH", true);
+        bool push_in = direct_out && crew_knob("HEVCDBK_HOST_PUSH", true);
         uint8_t *kout[3] = {nullptr, nullptr, nullptr}; /* where the kernel of plane i writes (device-side address), NULL = HBM + DMA */
         for (int i = 0; i < npl; i++) {
             any_staged |= !zc[i];
@@ -1118,13 +1172,7 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
         if (any_staged || push_in) { /* page-locked caller planes are pushed too: faster than a chain of DMAs for ONE frame */
             if (int rc = ensure_crew(ctx)) return rc;
             crew = ctx->crew;
-            if (push_in && ctx->dev_push.cap < frame_bytes) {
-                if (ctx->dev_push.p) (void)hipFree(ctx->dev_push.p);
-                ctx->dev_push.p = nullptr; ctx->dev_push.cap = 0;
-                if (hipExtMallocWithFlags(&ctx->dev_push.p, frame_bytes, hipDeviceMallocFinegrained) == hipSuccess) ctx->dev_push.cap = frame_bytes;
-                else { (void)hipGetLastError(); ctx->dev_push.p = nullptr; push_in = false; } /* no such memory here: ring + DMA */
-            }
-            if (push_in) dpush = (uint8_t *)ctx->dev_push.p;
+            if (push_in) dpush = push_buffer(ctx, frame_bytes); /* NULL: no such memory here -> ring + DMA */
         }
                 std::unique_ptr<CopyGroup[]> gin(new CopyGroup[ns]), gout(new CopyGroup[ns]);
         /* every path out of this block waits for the jobs it handed out (they point into gin / gout) and puts the crew to sleep */

@@ -145,14 +145,19 @@ int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, cons
     hipStream_t s = ctx->compute;
     hipEvent_t *ev = ctx->ev;
 
+    /* The frame's way in and out (round 4, as hevc_deblocking_filter's large-frame path): on a large-BAR device the staging crew
+     * writes the caller's rows straight into fine-grained HBM through the BAR and the kernels store their results straight into
+     * the page-locked ring, from which the crew copies them back -- no DMA in either direction; elsewhere ring + DMA both ways,
+     * the ring filled and emptied by the crew.  Not cut into strips: the bS derivation wants the whole picture's units first. */
     const auto wall0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < npl; i++) {
-        const size_t rb = (size_t)pw[i] * sb;
-        for (unsigned r = 0; r < ph[i]; r++)
-            std::memcpy((uint8_t *)ctx->pin[0].p + plane_off[i] + r * rb, (const uint8_t *)frame->plane[i] + r * frame->pitch[i], rb);
-    }
+    uint8_t *const ring = (uint8_t *)ctx->pin[0].p;
+    uint8_t *const dpush = push_buffer(ctx, frame_bytes);
+    uint8_t *const din = dpush ? dpush : (uint8_t *)ctx->dev[0].p;    /* what the kernels read */
+    uint8_t *const dout = dpush ? ring : (uint8_t *)ctx->dev[0].p;    /* what they write */
+    if (int rc = crew_copy_frame(ctx, frame, npl, pw, ph, sb, dpush ? dpush : ring, plane_off, false, dpush != nullptr)) return rc;
+    const double push_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
     HIP_TRY(ctx, hipEventRecord(ev[0], s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[0].p, ctx->pin[0].p, frame_bytes, hipMemcpyHostToDevice, s));
+    if (!dpush) HIP_TRY(ctx, hipMemcpyAsync(ctx->dev[0].p, ring, frame_bytes, hipMemcpyHostToDevice, s));
     if (dmap) HIP_TRY(ctx, hipMemcpyAsync(dmap, qp->map, map_rows * qp->map_stride, hipMemcpyHostToDevice, s));
     if (units) {
         /* device layout: ref0 | ref1 | mv0 | mv1 | flags (descending alignment) */
@@ -174,7 +179,8 @@ int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, cons
     for (int i = 0; i < npl; i++) {
         hevcdbk_device_planes p;
         std::memset(&p, 0, sizeof(p));
-        p.src = p.dst = (uint8_t *)ctx->dev[0].p + plane_off[i];
+        p.src = din + plane_off[i];
+        p.dst = dout + plane_off[i];
         p.pitch = (size_t)pw[i] * sb; p.frame_stride = plane_bytes[i]; p.n_frames = 1;
         p.plane_w = pw[i]; p.plane_h = ph[i]; p.bit_depth = frame->bit_depth; p.sample_bytes = sb;
         p.is_chroma = i != 0;
@@ -186,22 +192,18 @@ int hevc_deblocking_filter_h265(hevcdbk_context *ctx, hevcdbk_frame *frame, cons
         if (int rc = launch_h265(ctx, h, (int)sb, i != 0, HEVCDBK_KERNEL_AUTO, s)) return rc;
     }
     HIP_TRY(ctx, hipEventRecord(ev[2], s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin[0].p, ctx->dev[0].p, frame_bytes, hipMemcpyDeviceToHost, s));
+    if (!dpush) HIP_TRY(ctx, hipMemcpyAsync(ring, ctx->dev[0].p, frame_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(ev[3], s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    for (int i = 0; i < npl; i++) {
-        const size_t rb = (size_t)pw[i] * sb;
-        for (unsigned r = 0; r < ph[i]; r++)
-            std::memcpy((uint8_t *)frame->plane[i] + r * frame->pitch[i], (const uint8_t *)ctx->pin[0].p + plane_off[i] + r * rb, rb);
-    }
+    if (int rc = crew_copy_frame(ctx, frame, npl, pw, ph, sb, ring, plane_off, true, false)) return rc;
     const auto wall1 = std::chrono::steady_clock::now();
     if (timing) {
         float a = 0.f, b = 0.f, c = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&a, ev[0], ev[1]));
         HIP_TRY(ctx, hipEventElapsedTime(&b, ev[1], ev[2]));
         HIP_TRY(ctx, hipEventElapsedTime(&c, ev[2], ev[3]));
-        timing->exec_s = b * 1e-3;
-        timing->copy_s = (a + c) * 1e-3;
+        timing->exec_s = b * 1e-3;   /* with the BAR path the download is the kernels' own stores: inside exec_s */
+        timing->copy_s = (a + c) * 1e-3 + (dpush ? push_s : 0.0); /* uploads of bS / units / map (+ the frame: DMA, or the crew's writes) */
         timing->total_s = timing->exec_s + timing->copy_s;
         timing->pipelined_s = std::chrono::duration<double>(wall1 - wall0).count();
     }

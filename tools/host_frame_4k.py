@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--fresh", action="store_true", help="a newly allocated pageable frame for every call (as bench.py's e2e leg does)")
     ap.add_argument("--affinity", default="none", choices=["none", "near", "far"],
                     help="pin this process to the CPUs next to GPU 0 (sysfs local_cpulist), or to all the others, before the first HIP call")
+    ap.add_argument("--h265", action="store_true", help="the spec-exact entry (hevc_deblocking_filter_h265, bS 2 on every interior edge) instead")
     ap.add_argument("--diag", action="store_true", help="load libhevcdbk_diag.so: it reads HEVCDBK_HOST_STREAM_STORES / _AFFINITY / _THREADS (A/B runs)")
     ap.add_argument("--check", action="store_true", help="compare the last call's output with the oracle")
     args = ap.parse_args()
@@ -50,7 +51,7 @@ def main():
         src = [y0, u0, v0]
     else:
         src = [synth.blocky_plane(w, h, seed=5) if hasattr(synth, "blocky_plane") else synth.blocky_yuv420(w, h, seed=5)[0]]
-    out = {"width": w, "height": h, "memory": args.memory, "fresh_buffers": bool(args.fresh), "affinity": args.affinity, "env": {k: v for k, v in os.environ.items() if k.startswith("HEVCDBK_HOST")}, "planes": len(src), "bytes_each_way": int(sum(p.nbytes for p in src))}
+    out = {"width": w, "height": h, "memory": args.memory, "fresh_buffers": bool(args.fresh), "entry": "hevc_deblocking_filter_h265" if args.h265 else "hevc_deblocking_filter", "affinity": args.affinity, "env": {k: v for k, v in os.environ.items() if k.startswith("HEVCDBK_HOST")}, "planes": len(src), "bytes_each_way": int(sum(p.nbytes for p in src))}
     with deblock.Context(0) as ctx:
         if args.threads is not None and hasattr(ctx, "set_host_threads"):
             ctx.set_host_threads(args.threads)
@@ -66,6 +67,11 @@ def main():
                     ctx.host_register(b)
                 out["register_s"] = time.perf_counter() - t0
         walls, tms = [], []
+        if args.h265:
+            vb4 = np.zeros((h // 4, w // 8 + 1), np.uint8)
+            vb4[:, 1:w // 8] = 2
+            hb4 = np.zeros((h // 8 + 1, w // 4), np.uint8)
+            hb4[1:h // 8, :] = 2
         for _ in range(args.calls + 2):
             if args.fresh and args.memory == "pageable":
                 bufs = [p.copy() for p in src]
@@ -73,7 +79,10 @@ def main():
                 for b, p in zip(bufs, src):
                     b[:] = p
             t0 = time.perf_counter()
-            tm = ctx.filter_frame(*bufs, qp=args.qp)
+            if args.h265:
+                tm = ctx.filter_frame_h265(*bufs, qp=args.qp, vert_bs4=vb4, hor_bs4=hb4)
+            else:
+                tm = ctx.filter_frame(*bufs, qp=args.qp)
             walls.append(time.perf_counter() - t0)
             tms.append(tm)
         walls, tms = walls[2:], tms[2:]
@@ -84,7 +93,10 @@ def main():
             out[k + "_median"] = float(np.median([t[k] for t in tms]))
         if hasattr(ctx, "last_frame_trace"):
             out["last_call_strips"] = ctx.last_frame_trace()
-        if args.check:
+        if args.check and args.h265:
+            from oracle import h265
+            out["luma_bit_exact_vs_oracle"] = bool(np.array_equal(bufs[0], h265.filter_plane(src[0], args.qp, vb4, hb4)))
+        elif args.check:
             from oracle import oracle
             ok = True
             for i, (b, p) in enumerate(zip(bufs, src)):
