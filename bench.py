@@ -795,6 +795,18 @@ def e2e_legs(ctx, args, frames, barrier):
                 "sequence_pcie_GBps": 2 * w * h * sb * ns / t_seq / 1e9, "sequence_bit_exact": bool(seq_ok)})
     for p in pinned:
         ctx.free_pinned(p)
+    # the same sequence from ordinary pageable memory (what a caller that freads frames has): crew + BAR + ring, no DMA
+    pg = [frames[i].copy() for i in range(ns)]
+    ctx.filter_sequence([(p,) for p in pg[:4]], qp=qp, bit_depth=bd)  # warm-up (allocations, the crew's threads)
+    for i, p in enumerate(pg):
+        p[:] = frames[i]
+    barrier()
+    t_pg = ctx.filter_sequence([(p,) for p in pg], qp=qp, bit_depth=bd)
+    barrier()
+    pg_ok = all(np.array_equal(pg[i], oracle.filter_plane(frames[i], qp, bit_depth=bd, threads=8)) for i in (0, ns - 1))
+    out.update({"sequence_pageable_s": t_pg, "sequence_pageable_frames_per_s": ns / t_pg,
+                "sequence_pageable_GBps_each_way": w * h * sb * ns / t_pg / 1e9, "sequence_pageable_bit_exact": bool(pg_ok)})
+    out["sequence_bit_exact"] = out["sequence_bit_exact"] and bool(pg_ok)
     return out
 
 

@@ -1442,6 +1442,129 @@ extern "C" int hevc_deblocking_filter_sequence(hevcdbk_context *ctx, hevcdbk_fra
         row_bytes[k] = (size_t)pw[k] * sb;
         plane_bytes[k] = row_bytes[k] * ph[k];
     }
+    /*
+     * Large frames that ALL lie in ordinary pageable memory, on a large-BAR device (round 4): the single-frame operator's way in
+     * and out, with a frame where it has a strip.  The staging crew writes frame i straight into slot i % K of fine-grained HBM
+     * through the BAR, the kernels of frame i read that slot and store their results into slot i % K of a page-locked ring, the
+     * crew copies them out into the caller's planes -- three frames at different stages at any time, no DMA, no staging copy on
+     * the way in, and this thread only launches and polls.  A slot of HBM is written again once the kernels that read it have
+     * ended, a slot of the ring once its copy-out has ended.
+     */
+    {
+        size_t poff[3] = {0, 0, 0}, fbytes = 0;
+        for (int k = 0; k < npl; k++) {
+            poff[k] = fbytes;
+            fbytes = (fbytes + plane_bytes[k] + 255) & ~(size_t)255;
+        }
+        bool pageable = fbytes > ((size_t)2 << 20) && n_frames >= 2;
+        for (unsigned i = 0; i < n_frames && pageable; i++)
+            for (int k = 0; k < npl && pageable; k++) pageable = !is_pinned_host(frames[i].plane[k]);
+        uint8_t *dpush = pageable ? push_buffer(ctx, (size_t)K * fbytes) : nullptr;
+        if (dpush) {
+            if (int rc = grow_pinned(ctx, ctx->pin[1], (size_t)K * fbytes)) return rc;
+            uint8_t *const ring = (uint8_t *)ctx->pin[1].p;
+            if (int rc = ensure_crew(ctx)) return rc;
+            StageCrew *crew = ctx->crew;
+            if (int rc = ensure_timed_events(ctx, (size_t)K)) return rc;
+            hipEvent_t *done = ctx->timed_events.data(); /* per slot: the end of the kernels that read / wrote it last */
+            const auto wall0 = std::chrono::steady_clock::now();
+            if (int rc = stage_bs(ctx, W, H, chroma, bs, ctx->h2d)) return rc;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[12], ctx->h2d));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ctx->ev[12], 0));
+            std::unique_ptr<CopyGroup[]> gin(new CopyGroup[n_frames]), gout(new CopyGroup[n_frames]);
+            struct Scope { /* every path out waits for the jobs handed out and puts the crew to sleep */
+                StageCrew *c; CopyGroup *a, *b; unsigned n;
+                ~Scope() { for (unsigned i = 0; i < n; i++) { c->wait(a[i]); c->wait(b[i]); } c->end(); }
+            } scope{crew, gin.get(), gout.get(), n_frames};
+            const unsigned crew_n = crew->workers() ? crew->workers() : 1;
+            auto hand = [&](unsigned i, bool in) {
+                const hevcdbk_frame &fr = frames[i];
+                const size_t slot = (size_t)(i % K) * fbytes;
+                CopyGroup &g = in ? gin[i] : gout[i];
+                struct Piece { int k; unsigned a, b; };
+                Piece pc[3 * 16];
+                int np = 0;
+                for (int k = 0; k < npl; k++) {
+                    unsigned pieces = (unsigned)(plane_bytes[k] / ((size_t)512 << 10));
+                    const unsigned most = in ? (crew_n > 2 ? 4u : 2u) : 2 * crew_n; /* the BAR is saturated by two cores: few, long pieces */
+                    pieces = pieces < 1 ? 1 : pieces > most ? most : pieces;
+                    pieces = pieces > 16 ? 16 : pieces;
+                    for (unsigned q = 0; q < pieces; q++) pc[np++] = {k, (unsigned)((uint64_t)ph[k] * q / pieces), (unsigned)((uint64_t)ph[k] * (q + 1) / pieces)};
+                }
+                g.pending.store(np, std::memory_order_release);
+                for (int q = 0; q < np; q++) {
+                    const int k = pc[q].k;
+                    uint8_t *user = (uint8_t *)fr.plane[k] + (size_t)pc[q].a * fr.pitch[k];
+                    const size_t inner = slot + poff[k] + (size_t)pc[q].a * row_bytes[k];
+                    if (in) crew->submit({dpush + inner, user, row_bytes[k], fr.pitch[k], row_bytes[k], pc[q].b - pc[q].a, &g, true}, StageCrew::LANE_IN);
+                    else crew->submit({user, ring + inner, fr.pitch[k], row_bytes[k], row_bytes[k], pc[q].b - pc[q].a, &g, false}, StageCrew::LANE_OUT);
+                }
+            };
+            crew->begin();
+            const bool alone = crew->workers() == 0;
+            unsigned n_in = 0, n_launched = 0, n_out = 0, n_fin = 0;
+            while (n_fin < n_frames) {
+                bool progress = false;
+                /* copies in: slot i % K of HBM is free once the kernels of frame i - K have been seen to end */
+                if (n_in < n_frames && n_in < n_out + (unsigned)K) {
+                    hand(n_in++, true);
+                    progress = true;
+                }
+                /* launch: the frame is in HBM, and its ring slot has been copied out */
+                if (n_launched < n_in && gin[n_launched].pending.load(std::memory_order_acquire) == 0 && n_launched < n_fin + (unsigned)K) {
+                    const unsigned i = n_launched;
+                    const size_t slot = (size_t)(i % K) * fbytes;
+                    DbkArgs args[3];
+                    void *dplane[3] = {dpush + slot + poff[0], dpush + slot + poff[1], dpush + slot + poff[2]};
+                    for (int k = 0; k < npl; k++) {
+                        if (int rc = frame_plane_args(ctx, dplane, k, W, H, f0.bit_depth, sb, chroma, qp, nullptr, tables, args[k])) return rc;
+                        args[k].dst = ring + slot + poff[k]; /* the kernels store into page-locked host memory */
+                    }
+                    const int sbs[3] = {(int)sb, (int)sb, (int)sb};
+                    if (chroma && dbk_multi_supports(args, npl, sbs)) {
+                        dbk_set_next_launch_events(nullptr, done[i % K]);
+                        const hipError_t e = dbk_launch_packed_multi(args, npl, (int)sb, ctx->compute);
+                        dbk_set_next_launch_events(nullptr, nullptr);
+                        if (!hip_ok(ctx, e, "kernel launch")) return HEVCDBK_ERR_HIP;
+                    } else {
+                        for (int k = 0; k < npl; k++) {
+                            if (k == npl - 1) dbk_set_next_launch_events(nullptr, done[i % K]); /* one stream: the last launch ends last */
+                            const int rc = launch(ctx, args[k], (int)sb, k != 0, HEVCDBK_KERNEL_AUTO, ctx->compute);
+                            dbk_set_next_launch_events(nullptr, nullptr);
+                            if (rc) return rc;
+                        }
+                    }
+                    n_launched++;
+                    progress = true;
+                }
+                /* results landed: copies out */
+                if (n_out < n_launched) {
+                    const hipError_t q = hipEventQuery(done[n_out % K]);
+                    if (q == hipSuccess) {
+                        hand(n_out++, false);
+                        progress = true;
+                    } else if (q != hipErrorNotReady) {
+                        HIP_TRY(ctx, q);
+                    } else {
+                        (void)hipGetLastError();
+                    }
+                }
+                while (n_fin < n_out && gout[n_fin].pending.load(std::memory_order_acquire) == 0) {
+                    n_fin++;
+                    progress = true;
+                }
+                if (progress) continue;
+                if (alone && crew->help()) continue;
+                _mm_pause();
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->compute));
+            if (timing) {
+                std::memset(timing, 0, sizeof(*timing));
+                timing->pipelined_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+            }
+            return HEVCDBK_OK;
+        }
+    }
     for (int s = 0; s < K; s++) {
         for (int k = 0; k < npl; k++)
             if (int rc = grow_device(ctx, ctx->seq_dev[s][k], plane_bytes[k])) return rc;

@@ -662,6 +662,51 @@ def test_streaming_sequence_operator(ctx, oracle, golden_inputs):
         ctx.free_pinned(b)
 
 
+def test_streaming_sequence_of_large_pageable_frames(ctx, oracle):
+    """hevc_deblocking_filter_sequence on frames above 2 MiB that all lie in ordinary pageable memory: the round-4 pipeline (the
+    crew writes frame i into slot i % 3 of HBM through the BAR, the kernels store into slot i % 3 of a page-locked ring, the crew
+    copies out) -- 1 .. 8 frames (fewer and more than the three slots), luma only and Y+U+V, 8 and 10 bit, pitched rows whose
+    padding must stay untouched, a caller bS shared by the frames, 1 and 4 copying threads; every frame against the oracle.  One
+    page-locked plane in the sequence sends it down the DMA path instead: same results."""
+    from gpu_video_codec_amd import synth
+    try:
+        for threads in (4, 1):
+            ctx.set_host_threads(threads)
+            for (w, h, bd, n, chroma, pad) in ((1920, 1088, 8, 8, False, 0), (1920, 1088, 8, 5, True, 32), (2560, 1440, 10, 4, False, 16),
+                                               (3840, 2160, 8, 2, False, 0), (1920, 1088, 8, 1, True, 0)):
+                dt = np.uint8 if bd == 8 else np.uint16
+                vb, hb = oracle.lcg_bs(w, h, 3 + n)
+                frames, bufs, want = [], [], []
+                for i in range(n):
+                    pl = synth.blocky_yuv420(w, h, seed=100 + 7 * i + w, bit_depth=bd) if chroma else (synth.blocky_plane(w, h, seed=100 + 7 * i + w, bit_depth=bd),)
+                    want.append([oracle.filter_plane(p, 36, bit_depth=bd, is_chroma=k > 0, vert_bs=vb if k == 0 else None,
+                                                     hor_bs=hb if k == 0 else None, threads=8) for k, p in enumerate(pl)])
+                    bb = [np.full((p.shape[0], p.shape[1] + pad), 0x3C, dt) for p in pl]
+                    for b, p in zip(bb, pl):
+                        b[:, :p.shape[1]] = p
+                    bufs.append(bb)
+                    frames.append(tuple(b[:, :p.shape[1]] for b, p in zip(bb, pl)))
+                t = ctx.filter_sequence(frames, qp=36, bit_depth=bd, vert_bs=vb, hor_bs=hb)
+                assert t > 0
+                for i in range(n):
+                    for k in range(len(frames[i])):
+                        assert np.array_equal(frames[i][k], want[i][k]), (threads, w, h, bd, n, chroma, i, k)
+                        if pad:
+                            assert (bufs[i][k][:, -pad:] == 0x3C).all(), (threads, w, h, i, k)
+        # one page-locked frame among pageable ones: the DMA pipeline takes the sequence
+        w, h = 1920, 1088
+        src = [synth.blocky_plane(w, h, seed=300 + i) for i in range(4)]
+        pin = ctx.pinned_array((h, w), np.uint8)
+        planes = [(src[0].copy(),), (pin,), (src[2].copy(),), (src[3].copy(),)]
+        pin[:] = src[1]
+        ctx.filter_sequence(planes, qp=31)
+        for i in range(4):
+            assert np.array_equal(planes[i][0], oracle.filter_plane(src[i], 31, threads=8)), i
+        ctx.free_pinned(pin)
+    finally:
+        ctx.set_host_threads(0)
+
+
 def test_fused_launch_and_resident_default_bs(ctx, oracle):
     """Small 4:2:0 frames go out as one DMA in, one fused Y+U+V launch, one DMA out, and the default bS stays on
     the device between calls: alternate geometries, default and caller bS, pitched planes, and the streaming
