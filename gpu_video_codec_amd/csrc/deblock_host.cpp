@@ -1112,10 +1112,11 @@ int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hev
         const bool x_direct_in = crew_knob("HEVCDBK_HOST_DIRECT_IN", false);
         const int x_h2d_streams = crew_knob("HEVCDBK_HOST_H2D_STREAMS2", false) ? 2 : 1;
         const int x_k_streams = crew_knob("HEVCDBK_HOST_K_STREAMS2", false) ? 2 : 1;
-        if (x_direct_in || x_h2d_streams == 2 || x_k_streams == 2) { /* the bS / QP map upload (on h2d) comes first on every stream used */
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[12], 0));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[12], 0));
-        }
+        /* The bS / QP map upload (issued on h2d above, ev[12] behind it) comes first on every stream a strip's kernel may run on.
+         * With H2D DMAs the strips' own events on h2d implied it; a strip the crew writes through the BAR has no such event, and
+         * its kernel would otherwise be free to start before a caller's bS array or QP map has arrived. */
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->compute, ev[12], 0));
+        if (x_direct_in || x_h2d_streams == 2 || x_k_streams == 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, ev[12], 0));
         /* Pageable planes on a large-BAR device: the crew writes the caller's rows straight into HBM through the BAR (posted writes,
          * tools/ubench/bar_write.hip: 37-43 GB/s from one or two cores, as fast as filling the ring) -- no ring on the way in and no
          * H2D DMA with its set-up, event and cross-stream wait per strip.  The buffer is fine-grained device memory, so no cache of the
