@@ -185,6 +185,24 @@ def test_header_is_plain_c_and_example_links(L, tmp_path):
         assert r.returncode == 2 and "no CPU path" in r.stderr
 
 
+def test_host_frames_example_is_plain_c(L, tmp_path):
+    """examples/host_frames.c -- the reference-shaped host call with the round-4 entries (hevcdbk_set_host_threads,
+    hevcdbk_host_register, hevcdbk_last_frame_trace, the sequence operator) from strict C99; without a GPU it stops at
+    hevcdbk_create with its own exit code."""
+    import subprocess
+    from gpu_video_codec_amd import _lib, deblock
+    exe = str(tmp_path / "host_frames")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "host_frames.c"), "-L", libdir, "-lhevcdbk", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if deblock.device_count() > 0:
+        assert r.returncode == 0 and "all three ways agree byte for byte" in r.stdout, (r.stdout, r.stderr)
+    else:
+        assert r.returncode == 2 and "no CPU path" in r.stderr
+
+
 def test_cpp_class_mirror_compiles_and_keeps_the_reference_errors(L, tmp_path):
     """include/hevc_deblock.hpp (the ReadYuvFrame surface in C++): builds warning-free, and the reference's two constructor
     checks throw the reference's texts before any device is needed (cpu.h:43-48)."""

@@ -1104,3 +1104,38 @@ def test_cpp_class_mirror_against_golden_manifest(manifest, tmp_path):
             assert sha256(out.read_bytes()) == c["sha256"], (name, c)
             checked += 1
     assert checked >= 12
+
+
+def test_plain_c_host_frames_example(oracle, tmp_path):
+    """examples/host_frames.c on the GPU: a malloc'ed 4:2:0 4K frame, the same buffer registered, and a sequence of six, from
+    strict C99 through the C ABI; the example checks that the three ways agree byte for byte."""
+    import subprocess
+    from gpu_video_codec_amd import _lib
+    exe = str(tmp_path / "host_frames")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "host_frames.c"), "-L", libdir, "-lhevcdbk", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all three ways agree byte for byte" in r.stdout, (r.stdout, r.stderr)
+    assert "strip  0 plane 0 rows    0.." in r.stdout
+
+
+def test_host_frame_paths_a_large_bar_device_does_not_take(oracle):
+    """On MI355X the large-frame host call writes through the BAR and lets the kernels store into page-locked memory; a device
+    without a large BAR takes ring + H2D DMA instead, and a build without direct stores adds the D2H DMA.  Both forms stay in the
+    library, so both stay tested: the diagnostic build (the same sources; it reads HEVCDBK_HOST_PUSH / _DIRECT_OUT) filters a 4K
+    luma frame each way in a child process and compares with the oracle."""
+    import json
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "host_frame_4k.py")
+    for env in ({"HEVCDBK_HOST_PUSH": "0"}, {"HEVCDBK_HOST_PUSH": "0", "HEVCDBK_HOST_DIRECT_OUT": "0"}, {"HEVCDBK_HOST_STREAM_STORES": "0"},
+                {"HEVCDBK_HOST_AFFINITY": "0", "HEVCDBK_HOST_THREADS": "2"}):
+        r = subprocess.run([sys.executable, tool, "--calls", "3", "--diag", "--check"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["luma_bit_exact_vs_oracle"] is True, env
+        strips = d["last_call_strips"]
+        assert strips and (env.get("HEVCDBK_HOST_DIRECT_OUT") == "0") == any(s["d2h_ms"] > 0 for s in strips), env
+        assert (env.get("HEVCDBK_HOST_PUSH") == "0") == any(s["h2d_ms"] > 0 for s in strips), env
