@@ -302,6 +302,33 @@ struct LumaKEager {
     DBK_HD static LumaKEager load(const DBK_LDS uint32_t *tab, int ib, int it);
 };
 
+/* One beta, one of TWO tc values per lane (the spec-exact one-QP kernels in a wave that holds bS 1 next to bS 2: tc is the
+ * table value of QP + 2 (bS - 1)): both operand sets are wave-uniform, so each tc-dependent operand is computed twice on the
+ * scalar unit and picked per lane with one v_cndmask -- eleven selects per segment where LumaKEager::make spends about 45
+ * VALU instructions; the beta-dependent operands stay scalars (round 4). */
+template <bool H265>
+struct LumaKSel {
+    LumaKLazy<H265> z1, z2;
+    bool second; /* this lane takes z2 */
+    DBK_HD uint32_t filter_thr() const { return z1.filter_thr(); }
+    DBK_HD uint32_t km_dpq() const { return z1.km_dpq(); }
+    DBK_HD uint32_t km_e() const { return z1.km_e(); }
+    DBK_HD uint32_t side_thr() const { return z1.side_thr(); }
+    DBK_HD bool strong_possible() const { return true; } /* a zero threshold's bias says so by itself (LumaKEager::make) */
+    DBK_HD uint32_t kf() const { return second ? z2.kf() : z1.kf(); }
+    DBK_HD uint32_t snegc() const { return second ? z2.snegc() : z1.snegc(); }
+    DBK_HD pk sc2() const { return bits_pk(second ? pk_bits(z2.sc2()) : pk_bits(z1.sc2())); }
+    DBK_HD pk sk() const { return bits_pk(second ? pk_bits(z2.sk()) : pk_bits(z1.sk())); }
+    DBK_HD uint32_t nP() const { return second ? z2.nP() : z1.nP(); }
+    DBK_HD uint32_t nmask() const { return second ? z2.nmask() : z1.nmask(); }
+    DBK_HD pk nc() const { return bits_pk(second ? pk_bits(z2.nc()) : pk_bits(z1.nc())); }
+    DBK_HD pk nnegc() const { return bits_pk(second ? pk_bits(z2.nnegc()) : pk_bits(z1.nnegc())); }
+    DBK_HD pk nc2() const { return bits_pk(second ? pk_bits(z2.nc2()) : pk_bits(z1.nc2())); }
+    DBK_HD pk nnegc2() const { return bits_pk(second ? pk_bits(z2.nnegc2()) : pk_bits(z1.nnegc2())); }
+    DBK_HD pk nlim() const { return bits_pk(second ? pk_bits(z2.nlim()) : pk_bits(z1.nlim())); }
+    DBK_HD bool tc_zero() const { return second ? z2.tc_zero() : z1.tc_zero(); }
+};
+
 /*
  * Round 4: the per-lane operand set of a QP-map launch comes out of a TABLE.  Every operand is a function of beta alone or of
  * tc alone, beta and tc are table values of a QP index, so a launch has at most 52 (reference tables) / 54 (H.265 Table 8-12)

@@ -113,6 +113,11 @@ DBK_HD H265Uni h265_uni(int beta, int tc_bs1, int tc_bs2)
 template <bool WIDE = false>
 DBK_HD void luma_pairs_h265(Taps &a, Taps &b, int entry, int beta, int tc, int max_v);
 
+#if !DBK_DEV
+inline int &h265_sim_force_mixed_flag() { static int f = 0; return f; }
+inline bool h265_sim_force_mixed() { return h265_sim_force_mixed_flag() != 0; }
+#endif
+
 /* a wave-uniform flag the optimiser cannot relate to the expression it came from (two guards of opposite sense stay two
  * `if`s instead of being fused into one if / else) */
 DBK_HD bool opaque_uniform(bool v)
@@ -134,14 +139,21 @@ DBK_HD void luma_pairs_h265_uni(Taps &a, Taps &b, int entry, int beta, int tc, i
     if (any_lane(bs != 0 && keep)) luma_pairs_h265<WIDE>(a, b, keep ? entry : 0, beta, tc, max_v); /* entry 0: lane off */
     const bool fast = bs != 0 && !keep;
     const unsigned long long m1 = lane_ballot(fast && bs == 1), m2 = lane_ballot(fast && bs == 2);
+#if DBK_DEV
     const bool one_bs = m1 == 0ull || m2 == 0ull;
+#else
+    /* CPU build (tests/host_sim): a "wave" is one block and never holds both bS values; the test switch sends every block down
+     * the mixed-wave form instead, so that its arithmetic is checked against the oracle without a GPU */
+    const bool one_bs = (m1 == 0ull || m2 == 0ull) && !h265_sim_force_mixed();
+#endif
     if ((m1 | m2) != 0ull && one_bs) {
         /* the wave's one tc is picked on the scalar unit and the segment constants are built from it right here */
         luma_pairs<WIDE, true>(a, b, LumaKLazy<true>{u.beta, m2 != 0ull ? u.tc2 : u.tc1}, max_v, 0, fast);
     }
     if (opaque_uniform(!one_bs)) {
-        /* bS 1 and bS 2 side by side (inter pictures): the same core with per-lane operands, as the QP-map kernels run it */
-        luma_pairs<WIDE, false>(a, b, LumaKEager::make<true>(beta, tc), max_v, 0, fast);
+        /* bS 1 and bS 2 side by side (inter pictures): the same core with per-lane operands -- each tc-dependent operand one of
+         * two scalars, picked per lane (LumaKSel) */
+        luma_pairs<WIDE, false>(a, b, LumaKSel<true>{LumaKLazy<true>{u.beta, u.tc1}, LumaKLazy<true>{u.beta, u.tc2}, bs == 2}, max_v, 0, fast);
     }
 }
 

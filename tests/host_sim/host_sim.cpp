@@ -146,6 +146,15 @@ static void run(T *plane, int w, int h, long pitch_s, int is_chroma, const uint8
 }
 
 extern "C" int host_sim_have_packed(void) { return HAVE_PACKED; }
+/* the spec-exact one-QP kernels' form for waves that hold bS 1 next to bS 2 (LumaKSel), for every block */
+extern "C" void host_sim_h265_force_mixed(int on)
+{
+#if HAVE_PACKED
+    dbk::h265_sim_force_mixed_flag() = on;
+#else
+    (void)on;
+#endif
+}
 /* the launcher's operand-range predicate for the packed luma core (deblock_packed.h) */
 extern "C" int host_sim_packed_luma_tc_fits(int max_v, int tc_max)
 {

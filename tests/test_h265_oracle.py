@@ -251,6 +251,20 @@ def test_kernel_block_arithmetic_equals_picture_order_oracle(h265, sim):
                         assert np.array_equal(got, want), (w, h, bd, qp, c_idx, use_map, offs, packed)
                     cases += (got != plane).any()
     assert cases > 80  # the filter really ran in most cases
+    # round 4: the one-QP kernels' form for a wave that holds bS 1 next to bS 2 (LumaKSel: every tc-dependent operand one of two
+    # scalars, picked per lane) -- on the CPU a "wave" is one block, so the simulator sends EVERY block through that form
+    sim.host_sim_h265_force_mixed(1)
+    try:
+        for (w, h, bd) in [(136, 72, 8), (64, 64, 10), (72, 40, 12)]:
+            plane = synth.blocky_plane(w, h, seed=3 * w + bd, bit_depth=bd)
+            for qp in (18, 27, 37, 46, 51):
+                vb, hb = full_bs(h265, w, h, 0, rng)
+                offs = dict(tc_off=int(rng.randint(-6, 7)), beta_off=int(rng.randint(-6, 7)), c_qp_off=0)
+                want = h265.filter_plane(plane, qp, vb, hb, bit_depth=bd, tc_offset_div2=offs["tc_off"], beta_offset_div2=offs["beta_off"])
+                got = sim_filter(sim, plane, qp, vb, hb, bit_depth=bd, packed=1, **offs)
+                assert np.array_equal(got, want), ("mixed form", w, h, bd, qp, offs)
+    finally:
+        sim.host_sim_h265_force_mixed(0)
     # samples hugging 0 and 255 with large tc: the conditional Clip1 of the packed form must fire
     w, h = 64, 32
     base = np.where(rng.randint(0, 2, (h // 8, w // 8)) == 0, 2, 252)
