@@ -401,7 +401,17 @@ def extra_configs(ctx, args, frames, batch, variant):
         abytes = F5 * algorithmic_bytes_per_frame(w5, h5, 2)
         want5 = oracle.filter_plane(f5[F5 - 1], qp, bit_depth=bd5, threads=8)
         for key, storage, memo in (("config5_8k_10bit", (batch.src, batch.dst), "the headline batch's frame pool, reused"),
-                                   ("config5_8k_10bit_fresh_pool", None, "a pool allocated for this figure")):
+                                   ("config5_8k_10bit_fresh_pool", None, "a pool allocated for this figure"),
+                                   ("config5_8k_10bit_probed_pool", "probe", "a destination pool chosen among 6 allocations by the filter's "
+                                    "own time on each (hevcdbk_device_malloc_probed): what a decoder that keeps its output pool can have")):
+            probed = None
+            if storage == "probe":
+                src5 = ctx.alloc(F5 * w5 * h5 * 2)
+                tmp = deblock.DeviceBatch(ctx, w5, h5, F5, bit_depth=bd5, storage=(src5, src5))   # geometry + bS for the probe launch
+                dst5, probe_best, probe_worst = ctx.alloc_probed(tmp.planes(), qp, 6)
+                tmp.free()
+                probed = (src5, dst5, probe_best, probe_worst)
+                storage = (src5, dst5)
             b5 = deblock.DeviceBatch(ctx, w5, h5, F5, bit_depth=bd5, storage=storage)
             b5.upload_all(f5)
             ms, info = settled_run(ctx, [b5.planes()], qp, max(steps, 100), variant, args)
@@ -412,6 +422,10 @@ def extra_configs(ctx, args, frames, batch, variant):
                 "parity": "unpinned beyond 8 bit (the reference is 8-bit only, SURVEY 8c): checked against the CPU restatement"})
             out[key]["luma_frames_per_s"] = F5 / (out[key]["ms_per_step"] * 1e-3)
             b5.free()
+            if probed:
+                out[key]["probe_best_ms"], out[key]["probe_worst_ms"] = probed[2], probed[3]
+                probed[0].free()
+                probed[1].free()
         del f5
     return out
 

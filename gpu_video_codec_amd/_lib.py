@@ -40,7 +40,7 @@ EXPORTS = [
     "hevc_deblock_sao_device", "hevc_deblock_sao_h265_device",
     "hevc_deblock_sao_device_planes", "hevc_deblock_sao_h265_device_planes",
     "hevcdbk_set_host_threads", "hevcdbk_get_host_threads", "hevcdbk_host_register", "hevcdbk_host_unregister",
-    "hevcdbk_last_frame_trace",
+    "hevcdbk_last_frame_trace", "hevcdbk_device_malloc_probed",
 ]
 
 
@@ -223,6 +223,8 @@ def lib():
         L.hevcdbk_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.hevcdbk_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
         L.hevcdbk_last_frame_trace.argtypes = [C.c_void_p, C.POINTER(StripTrace), C.c_uint, C.POINTER(C.c_uint)]
+        L.hevcdbk_device_malloc_probed.argtypes = [C.c_void_p, C.POINTER(DevicePlanes), C.c_uint, C.POINTER(Tables), C.c_uint,
+                                                   C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _lib = L
     return _lib
 

@@ -942,6 +942,65 @@ int hevcdbk_device_replay(hevcdbk_context *ctx, const hevcdbk_device_planes *pla
     return HEVCDBK_OK;
 }
 
+int hevcdbk_device_malloc_probed(hevcdbk_context *ctx, const hevcdbk_device_planes *probe, unsigned qp, const hevcdbk_tables *tables,
+                                 unsigned candidates, void **dptr, float *best_ms, float *worst_ms)
+{
+    if (!ctx || !probe || !dptr || candidates == 0 || candidates > 16 || !probe->src || probe->n_frames == 0) return HEVCDBK_ERR_ARG;
+    *dptr = nullptr;
+    const size_t bytes = probe->frame_stride * (size_t)(probe->n_frames - 1) + probe->pitch * (size_t)probe->plane_h;
+    if (bytes == 0) return HEVCDBK_ERR_ARG;
+    if (int rc = bind(ctx)) return rc;
+    void *cand[16] = {};
+    float t[16];
+    int rc = HEVCDBK_OK;
+    unsigned n = 0;
+    for (; n < candidates; n++) {
+        if (hipMalloc(&cand[n], bytes) != hipSuccess) { /* fewer candidates than asked for is not an error as long as there is one */
+            (void)hipGetLastError();
+            cand[n] = nullptr;
+            break;
+        }
+    }
+    if (n == 0) return HEVCDBK_ERR_NOMEM;
+    /* the card idles at a few hundred MHz: launches go out for 100-200 ms first (into candidate 0), so that the first candidates
+     * are not timed at a lower clock than the last; then two passes over the candidates, the best of three launches each */
+    {
+        hevcdbk_device_planes p = *probe;
+        p.dst = cand[0];
+        hevcdbk_replay r;
+        std::memset(&r, 0, sizeof(r));
+        r.settle_min_ms = 100.0;
+        r.settle_max_ms = 200.0;
+        rc = hevcdbk_device_replay(ctx, &p, 1, qp, tables, HEVCDBK_KERNEL_AUTO, &r, nullptr);
+    }
+    for (unsigned k = 0; k < n; k++) t[k] = 1e30f;
+    for (int pass = 0; pass < 2 && rc == HEVCDBK_OK; pass++)
+        for (unsigned k = 0; k < n && rc == HEVCDBK_OK; k++) {
+            hevcdbk_device_planes p = *probe;
+            p.dst = cand[k];
+            hevcdbk_replay r;
+            std::memset(&r, 0, sizeof(r));
+            r.warmup = 1;
+            r.steps = 3;
+            float ms[3] = {0.f, 0.f, 0.f};
+            rc = hevcdbk_device_replay(ctx, &p, 1, qp, tables, HEVCDBK_KERNEL_AUTO, &r, ms);
+            for (int i = 0; i < 3; i++) t[k] = ms[i] < t[k] ? ms[i] : t[k];
+        }
+    unsigned best = 0, worst = 0;
+    if (rc == HEVCDBK_OK)
+        for (unsigned k = 1; k < n; k++) {
+            if (t[k] < t[best]) best = k;
+            if (t[k] > t[worst]) worst = k;
+        }
+    for (unsigned k = 0; k < n; k++)
+        if (rc != HEVCDBK_OK || k != best) (void)hipFree(cand[k]);
+    if (rc != HEVCDBK_OK) return rc;
+    *dptr = cand[best];
+    if (best_ms) *best_ms = t[best];
+    if (worst_ms) *worst_ms = t[worst];
+    return HEVCDBK_OK;
+}
+
 int hevcdbk_device_pci_bus_id(const hevcdbk_context *ctx, char *buf, size_t len)
 {
     if (!ctx || !buf || len < 13) return HEVCDBK_ERR_ARG;

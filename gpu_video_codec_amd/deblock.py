@@ -104,6 +104,13 @@ class DeviceBuffer:
             _lib.lib().hevcdbk_device_free(self.ctx.handle, self.ptr)
             self.ptr = None
 
+    @classmethod
+    def adopt(cls, ctx, ptr, nbytes):
+        """A DeviceBuffer around memory the library allocated (hevcdbk_device_malloc_probed); free() releases it."""
+        b = cls.__new__(cls)
+        b.ctx, b.nbytes, b.ptr = ctx, int(nbytes), ptr
+        return b
+
 
 class Context:
     """hevcdbk_context: one per HIP device; owns the compute stream and the two copy streams."""
@@ -175,6 +182,16 @@ class Context:
                                                C.byref(tm) if want_timing else None)
         _chk(rc, self.handle)
         return {"exec_s": tm.exec_s, "total_s": tm.total_s, "copy_s": tm.copy_s, "pipelined_s": tm.pipelined_s}
+
+    def alloc_probed(self, planes, qp, candidates=6, *, tc_table=None, beta_table=None):
+        """hevcdbk_device_malloc_probed: a destination pool for launches like `planes` (a DevicePlanes; its dst is ignored), the
+        fastest of `candidates` allocations by the filter's own time on each.  Returns (DeviceBuffer, best_ms, worst_ms)."""
+        t, _k = _tables(tc_table, beta_table)
+        p, best, worst = C.c_void_p(), C.c_float(), C.c_float()
+        _chk(_lib.lib().hevcdbk_device_malloc_probed(self.handle, C.byref(planes), int(qp), None if t is None else C.byref(t),
+                                                     int(candidates), C.byref(p), C.byref(best), C.byref(worst)), self.handle)
+        nbytes = planes.frame_stride * (planes.n_frames - 1) + planes.pitch * planes.plane_h
+        return DeviceBuffer.adopt(self, p.value, nbytes), best.value, worst.value
 
     # -- host side of filter_frame on large pageable frames --------------------------------------
     def set_host_threads(self, n):

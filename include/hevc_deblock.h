@@ -251,6 +251,22 @@ HEVCDBK_API int hevcdbk_memset_d(hevcdbk_context *ctx, void *dptr, int value, si
 HEVCDBK_API int hevcdbk_synchronize(hevcdbk_context *ctx); /* all three streams */
 HEVCDBK_API void *hevcdbk_compute_stream(hevcdbk_context *ctx); /* hipStream_t */
 
+/*
+ * A destination pool chosen among several allocations.  Where the driver puts a buffer's physical pages decides how fast the
+ * kernels for 16-bit containers write into it: identical launches run up to 13 % apart from one allocation to the next, the
+ * difference follows the DESTINATION buffer, stays with it for its lifetime, and nothing cheaper than the filter itself
+ * predicts it (a fill or a DMA copy does not; it is not address translation: profiles/r04/placement.md).  For a pool that lives
+ * long -- a decoder's output pictures -- it pays to look once: `probe` describes a launch exactly as
+ * hevc_deblocking_filter_device takes it (its dst field is ignored); the function allocates `candidates` (1 .. 16) buffers of the
+ * size that launch writes (frame_stride * (n_frames - 1) + pitch * plane_h), runs the launch into each (one warm-up, three
+ * timed), keeps the fastest, frees the others and returns it in *dptr (release with hevcdbk_device_free).  best_ms / worst_ms
+ * (may be NULL): the fastest and the slowest candidate's kernel time.  The reference allocates its device planes once per run
+ * with cudaMalloc (gpu.cu:1110-1133) and has no such choice to make.
+ */
+HEVCDBK_API int hevcdbk_device_malloc_probed(hevcdbk_context *ctx, const hevcdbk_device_planes *probe, unsigned qp,
+                                             const hevcdbk_tables *tables, unsigned candidates, void **dptr, float *best_ms,
+                                             float *worst_ms);
+
 /* Timed replay for benchmarks: launches the device operator `steps` times back-to-back on the
  * compute stream with a HIP event pair around EACH launch, synchronises once at the end and
  * writes the per-launch kernel durations (milliseconds) to kernel_ms[steps].  (= hevcdbk_device_replay with no

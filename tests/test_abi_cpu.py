@@ -339,3 +339,5 @@ def test_host_side_entries_reject_bad_arguments_without_a_device(L):
     assert L.hevcdbk_host_register(None, None, 0) == _lib.ERR_ARG
     assert L.hevcdbk_host_unregister(None, None) == _lib.ERR_ARG
     assert L.hevcdbk_last_frame_trace(None, None, 0, C.byref(n)) == _lib.ERR_ARG
+    p = C.c_void_p(5)
+    assert L.hevcdbk_device_malloc_probed(None, None, 30, None, 4, C.byref(p), None, None) == _lib.ERR_ARG

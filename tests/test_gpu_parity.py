@@ -1139,3 +1139,30 @@ def test_host_frame_paths_a_large_bar_device_does_not_take(oracle):
         strips = d["last_call_strips"]
         assert strips and (env.get("HEVCDBK_HOST_DIRECT_OUT") == "0") == any(s["d2h_ms"] > 0 for s in strips), env
         assert (env.get("HEVCDBK_HOST_PUSH") == "0") == any(s["h2d_ms"] > 0 for s in strips), env
+
+
+def test_probed_destination_pool(ctx, oracle):
+    """hevcdbk_device_malloc_probed: a destination pool picked among candidate allocations by timing the filter on each.  The
+    pool it returns is ordinary device memory of the size the launch writes: the launch into it equals the oracle (8-bit and
+    10-bit batches, one candidate and several), best <= worst, and bad arguments are refused before anything is allocated."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    for (w, h, bd, n, cands) in ((640, 360 // 8 * 8, 8, 3, 1), (1280, 720, 10, 4, 5)):
+        fr = np.stack([synth.blocky_plane(w, h, seed=60 + f + bd, bit_depth=bd) for f in range(n)])
+        b = deblock.DeviceBatch(ctx, w, h, n, bit_depth=bd, per_frame_bs=False)
+        b.upload_all(fr)
+        pool, best, worst = ctx.alloc_probed(b.planes(), 33, cands)
+        assert pool.ptr and pool.nbytes == b.frame_bytes * n and 0 < best <= worst
+        p = b.planes()
+        p.dst = pool.ptr
+        pool.upload(np.zeros(pool.nbytes, np.uint8))
+        ctx.filter_device(p, 33)
+        ctx.synchronize()
+        got = pool.download(dtype=fr.dtype).reshape(n, h, w)
+        for f in range(n):
+            assert np.array_equal(got[f], oracle.filter_plane(fr[f], 33, bit_depth=bd, threads=4)), (bd, f)
+        for bad in (0, 17):
+            with pytest.raises(deblock.DeblockError) as e:
+                ctx.alloc_probed(b.planes(), 33, bad)
+            assert e.value.code == _lib.ERR_ARG
+        pool.free()
+        b.free()

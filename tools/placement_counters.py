@@ -26,7 +26,12 @@ COUNTERS2 = ["TCP_UTCL1_SERIALIZATION_STALL", "TCP_UTCL1_THRASHING_STALL", "TCP_
 
 
 def child(a):
-    from gpu_video_codec_amd import deblock, synth
+    from gpu_video_codec_amd import deblock, synth, _lib
+    variant = _lib.KERNEL_AUTO
+    if a.diag is not None or a.variant == "copy":   # the diagnostic build: the kernel's loads and stores with no arithmetic, knobs
+        _lib.use_diagnostic_library(a.diag or None)
+        if a.variant == "copy":
+            variant = _lib.DIAG_KERNEL_COPY
     w, h, bd, F = a.width, a.height, a.bit_depth, a.frames
     sb = 1 if bd == 8 else 2
     ctx = deblock.Context(0)
@@ -46,7 +51,7 @@ def child(a):
                        "src_mod_1GiB": b.src.ptr % (1 << 30)} for b in pools], "order": [], "event_ms": []}
     for rnd in range(a.rounds):
         for k, b in enumerate(pools):
-            ms, _info = ctx.replay([b.planes()], a.qp, a.reps, warmup=2, settle_min_ms=0, settle_max_ms=a.settle_ms)
+            ms, _info = ctx.replay([b.planes()], a.qp, a.reps, warmup=2, settle_min_ms=0, settle_max_ms=a.settle_ms, variant=variant)
             plan["order"].append({"pool": k, "launches": int(_info["settle_launches"]) + 2 + a.reps, "timed": a.reps})
             plan["event_ms"].append({"pool": k, "round": rnd, "mean_ms": float(np.mean(ms)), "min_ms": float(np.min(ms))})
     if a.matrix:
@@ -57,11 +62,11 @@ def child(a):
             for j, bd_ in enumerate(pools):
                 p = bs_.planes()
                 p.dst = bd_.dst.ptr
-                ms, _info = ctx.replay([p], a.qp, a.reps, warmup=2, settle_min_ms=0, settle_max_ms=a.settle_ms)
+                ms, _info = ctx.replay([p], a.qp, a.reps, warmup=2, settle_min_ms=0, settle_max_ms=a.settle_ms, variant=variant)
                 row.append(round(float(np.mean(ms)), 4))
             p = bs_.planes()
             p.dst = bs_.src.ptr
-            ms, _info = ctx.replay([p], a.qp, a.reps, warmup=2, settle_min_ms=0, settle_max_ms=a.settle_ms)
+            ms, _info = ctx.replay([p], a.qp, a.reps, warmup=2, settle_min_ms=0, settle_max_ms=a.settle_ms, variant=variant)
             row.append(round(float(np.mean(ms)), 4))   # last column: in place (dst = src)
             plan["matrix_ms"].append(row)
     print("PLAN " + json.dumps(plan), flush=True)
@@ -81,6 +86,8 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=60.0)
     ap.add_argument("--interleave-junk", action="store_true")
     ap.add_argument("--matrix", action="store_true", help="child only, no profiler: every source pool against every destination pool")
+    ap.add_argument("--variant", default="filter", choices=["filter", "copy"], help="copy: the diagnostic build's copy variant of the kernel")
+    ap.add_argument("--diag", default=None, help="knobs of the diagnostic build (csrc/hevcdbk_diag.h), e.g. align")
     ap.add_argument("--tag", default="cfg5")
     ap.add_argument("--set", type=int, default=1, choices=[1, 2], help="counter set (a process = one placement: one set per run)")
     a = ap.parse_args()
