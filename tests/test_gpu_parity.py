@@ -1015,18 +1015,21 @@ def test_staging_crew_sizes_on_large_pageable_frames(ctx, oracle):
     frame in pitched rows; results, the untouched row padding, and the strip record of the call (hevcdbk_last_frame_trace:
     the strips tile every plane exactly, first strips shorter than later ones, all phases in order)."""
     from gpu_video_codec_amd import synth
-    y4k = synth.blocky_plane(3840, 2160, seed=81)
-    want4k = oracle.filter_plane(y4k, 32, threads=8)
+    # three DIFFERENT frames go through the same HBM / ring buffers call after call: a stale line of the previous frame anywhere
+    # between the host's writes and the kernel's reads (the crew writes HBM through the BAR, behind the GPU's caches) would show
+    y4ks = [synth.blocky_plane(3840, 2160, seed=81 + 5 * i) for i in range(3)]
+    want4ks = [oracle.filter_plane(y, 32, threads=8) for y in y4ks]
+    y4k = y4ks[0]
     y, u, v = synth.blocky_yuv420(1920, 1088, seed=82)
     want = oracle.split_yuv420(oracle.filter_yuv420(oracle.join_yuv420(y, u, v), 1920, 1088, 36), 1920, 1088)
     try:
         for n in (1, 2, 4, 8):
             ctx.set_host_threads(n)
             assert ctx.host_threads() == n
-            for rep in range(3):  # the crew sleeps between calls and is woken again
-                g = y4k.copy()
+            for rep in (0, 1, 2, 1, 0, 2):  # the crew sleeps between calls and is woken again
+                g = y4ks[rep].copy()
                 t = ctx.filter_frame(g, qp=32)
-                assert np.array_equal(g, want4k), (n, rep)
+                assert np.array_equal(g, want4ks[rep]), (n, rep)
             tr = ctx.last_frame_trace()
             assert len(tr) >= 4 and tr[0]["row_begin"] == 0 and tr[-1]["row_end"] == 2160
             assert all(a["row_end"] == b["row_begin"] for a, b in zip(tr, tr[1:]))
