@@ -11,13 +11,93 @@ from gpu_video_codec_amd import deblock, synth, _lib
 from oracle import oracle, h265
 
 
+def host_large(ctx, rng, cases):
+    """Round 4: the host-frame operators on LARGE frames (the crew / BAR / ring pipeline: above 2 MiB), drawn at random -- geometry,
+    bit depth, luma only or 4:2:0, row padding, caller bS, a per-CTU QP map, 1..6 copying threads, some planes page-locked or
+    registered, single calls and sequences, and the spec-exact host entry; every plane against the oracles."""
+    bad = 0
+    for case in range(cases):
+        w = int(16 * rng.randint(80, 257))          # 1280 .. 4096
+        h = int(16 * rng.randint(68, 137))          # 1088 .. 2176
+        bd = int(rng.choice([8, 8, 10, 12]))
+        chroma = bool(rng.randint(0, 2))
+        pad = int(rng.choice([0, 0, 16, 40]))
+        qp = int(rng.randint(20, 52))
+        use_map = rng.randint(0, 4) == 0
+        user_bs = bool(rng.randint(0, 2))
+        threads = int(rng.choice([1, 2, 3, 4, 6]))
+        kind = rng.choice(["frame", "frame", "sequence", "h265"])
+        if kind != "frame":
+            use_map = False
+        dt = np.uint8 if bd == 8 else np.uint16
+        ctx.set_host_threads(threads)
+        tag = dict(case=case, w=w, h=h, bd=bd, chroma=chroma, pad=pad, qp=qp, use_map=use_map, user_bs=user_bs, threads=threads, kind=str(kind))
+        nfr = int(rng.randint(2, 6)) if kind == "sequence" else 1
+        qmap = rng.randint(max(qp - 8, 0), min(qp + 8, 51) + 1, ((h + 63) // 64, (w + 63) // 64)).astype(np.uint8) if use_map else None
+        vb, hb = oracle.lcg_bs(w, h, int(rng.randint(1, 1000))) if user_bs else (None, None)
+        frames, bufs, wants, locked = [], [], [], []
+        for f in range(nfr):
+            pl = synth.blocky_yuv420(w, h, seed=int(rng.randint(1, 1 << 30)), bit_depth=bd) if chroma else \
+                (synth.blocky_plane(w, h, seed=int(rng.randint(1, 1 << 30)), bit_depth=bd),)
+            if kind == "h265":
+                vb4 = (rng.randint(0, 3, h265.num_vert_bs(w, h)) | (rng.randint(0, 10, h265.num_vert_bs(w, h)) == 0) * 4).astype(np.uint8)
+                hb4 = (rng.randint(0, 3, h265.num_hor_bs(w, h)) | (rng.randint(0, 10, h265.num_hor_bs(w, h)) == 0) * 8).astype(np.uint8)
+                wants.append([h265.filter_plane(pl[0], min(qp, 51), vb4, hb4, bit_depth=bd)])
+                pl = (pl[0],)
+            else:
+                wants.append([oracle.filter_plane(p, 0 if use_map else qp, bit_depth=bd, is_chroma=k > 0, vert_bs=vb if k == 0 else None,
+                                                  hor_bs=hb if k == 0 else None, qp_map=qmap, threads=8) for k, p in enumerate(pl)])
+            bb = []
+            for p in pl:
+                shape = (p.shape[0], p.shape[1] + pad)
+                how = int(rng.randint(0, 6)) if kind == "frame" else 0     # 0-3 pageable, 4 page-locked, 5 registered
+                b = ctx.pinned_array(shape, dt) if how == 4 else np.empty(shape, dt)
+                if how == 5:
+                    ctx.host_register(b)
+                locked.append((how, b))
+                b[:] = 0x3C
+                b[:, :p.shape[1]] = p
+                bb.append(b)
+            bufs.append(bb)
+            frames.append(tuple(b[:, :b.shape[1] - pad] if pad else b for b in bb))
+        try:
+            if kind == "frame":
+                ctx.filter_frame(*frames[0], qp=0 if use_map else qp, bit_depth=bd, vert_bs=vb, hor_bs=hb, qp_map=qmap)
+            elif kind == "sequence":
+                ctx.filter_sequence(frames, qp=qp, bit_depth=bd, vert_bs=vb, hor_bs=hb)
+            else:
+                ctx.filter_frame_h265(frames[0][0], qp=min(qp, 51), bit_depth=bd, vert_bs4=vb4, hor_bs4=hb4)
+            for f in range(nfr):
+                for k in range(len(frames[f])):
+                    if not np.array_equal(frames[f][k], wants[f][k]):
+                        print("MISMATCH host-large", f, k, tag)
+                        bad += 1
+                    if pad and not (bufs[f][k][:, -pad:] == 0x3C).all():
+                        print("PADDING TOUCHED host-large", f, k, tag)
+                        bad += 1
+        finally:
+            for how, b in locked:
+                if how == 4:
+                    ctx.free_pinned(b)
+                elif how == 5:
+                    ctx.host_unregister(b)
+        if case % 10 == 9:
+            print("soak host-large: %d cases, %d mismatches" % (case + 1, bad), flush=True)
+    ctx.set_host_threads(0)
+    print("soak host-large done: %d cases, %d mismatches" % (cases, bad))
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--host-large", type=int, default=0, metavar="N", help="N random LARGE host frames / sequences through the host operators instead")
     a = ap.parse_args()
     rng = np.random.RandomState(a.seed)
     ctx = deblock.Context(0)
+    if a.host_large:
+        sys.exit(1 if host_large(ctx, rng, a.host_large) else 0)
     bad = 0
     for case in range(a.cases):
         w = int(8 * rng.choice([rng.randint(1, 20), rng.randint(60, 70), rng.randint(125, 135), rng.randint(1, 600)]))
