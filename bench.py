@@ -20,10 +20,18 @@ K timed launches are already queued behind it, the back bracket one stream synch
 kernels + sync, gpu.cu:1266-1291).  ms_per_step = that wall clock / K.  With N > 1 ranks the ranks settle, meet in a
 barrier, and every rank then runs [100 ms re-settle][warm-up][K timed] uninterrupted; value uses the MAX over ranks.
 
+Every rank (round 4): pins itself to the CPUs next to its GPU BEFORE its first HIP call (shard.pin_to_gpu_cpus), filters its
+share of ONE seeded frame set (frames dealt f mod N), hashes 16 of its output frames -- rank 0 filters two frames of every
+other rank on ITS GPU again and compares (`cross_rank.frames_equal_1gpu`) -- and runs the PCIe-inclusive legs between common
+barriers: the reference-shaped host call on one pageable frame, the sequence operator from page-locked and from pageable
+planes (`e2e_host_frame`, `per_rank[*].e2e_*`; never `value`).
+
 After the headline measurement, rank 0 of a one-GPU run adds (each with its own bit-exactness spot check):
   extra_configs   the same kernel at 64 frames per launch (a decoder-sized batch), BASELINE config 4 as whole
                   4:2:0 frames (Y + U + V), deblocking + SAO in one kernel against the two launches it replaces
-                  (SURVEY 8f rank 4) and config 5 (7680x4320 10-bit luma), with ms_per_step / frac / bytes;
+                  (SURVEY 8f rank 4), BASELINE configs 1 and 3 on the reference's bundled inputs (config3 also at 64 x 4K with a
+                  QP map) and config 5 (7680x4320 10-bit luma: the headline pool reused, a fresh pool, and a destination pool
+                  chosen by hevcdbk_device_malloc_probed), with ms_per_step / frac / bytes;
   cpu_baseline    the reference's thread ladder (main.cu:36-83: 1, 2, 4, 6, 8 threads, plus all host cores):
                   >= 30 repetitions each, min and median, filter-only window (main.cu:41-43);
   reference_table the reference README's own line (README.md:19-24): 352x288 QP 35 Y+U+V, CPU 1T, CPU OpenMP,
