@@ -822,8 +822,11 @@ __global__ __launch_bounds__(1024) void dbk_packed16_h265_kernel(const DbkH265Ar
  * both halves of every such line on one CU / one XCD L2, where the partial writes merge before
  * write-back.
  */
+/* (round 4: forcing the QP-map instantiations to 8 waves per SIMD -- amdgpu_waves_per_eu(8, 8): 64 VGPRs and 32-64 bytes of
+ * scratch in a rarely taken path -- measured the same as the compiler's own 69-72 VGPRs / 7 waves / no scratch in three
+ * alternating runs each, 0.658-0.662 against 0.661-0.664 and 0.639-0.642 against 0.639-0.646: not kept) */
 template <bool CHROMA, int MODE, bool NT, bool LINEAR, bool QPMAP>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(QPMAP && !CHROMA ? 8 : 1, 8))) void dbk_packed_kernel(const DbkArgs a)
+__global__ __launch_bounds__(1024) void dbk_packed_kernel(const DbkArgs a)
 {
     uint32_t *kt = nullptr;
     if constexpr (QPMAP && !CHROMA && (MODE == 0 || MODE == 3)) {
@@ -854,7 +857,7 @@ __device__ __forceinline__ void packed_h265_dispatch(const DbkH265Args &h)
     else packed_body<CHROMA, 2, false, 2, QPMAP>(a, c.by, c.f, c.bx, c.active, c.by0, &h, kt);
 }
 template <bool CHROMA, bool LINEAR, bool QPMAP>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(QPMAP && !CHROMA ? 8 : 1, 8))) void dbk_packed_h265_kernel(const DbkH265Args h)
+__global__ __launch_bounds__(1024) void dbk_packed_h265_kernel(const DbkH265Args h)
 {
     packed_h265_dispatch<CHROMA, LINEAR, QPMAP>(h);
 }
