@@ -3,9 +3,10 @@
  *
  * Replaces the host side of the reference's GPU path (gpu.cu:35-77 globals, 1074-1203
  * Initialize/Release, 1230-1306 ExecuteGpu) with a re-entrant per-device context:
- * pinned hipHostMalloc staging + hipMemcpyAsync on two copy side streams, kernels on a compute
- * stream, events between them so the H2D of the chroma planes overlaps the luma kernel and the
- * D2H of luma overlaps the chroma kernels.
+ * large frames cut into strips that a crew of host threads (host_crew.h) writes into HBM through
+ * the PCIe BAR while the kernels of earlier strips store into page-locked memory (round 4), pinned
+ * hipHostMalloc staging + hipMemcpyAsync on two copy side streams where there is no large BAR,
+ * kernels on a compute stream.
  *
  * There is deliberately no CPU implementation of the filter in this library.
  *
@@ -1013,7 +1014,7 @@ int hevcdbk_device_pci_bus_id(const hevcdbk_context *ctx, char *buf, size_t len)
     return HEVCDBK_OK;
 }
 
-/* ---- host-frame operator: pinned staging + async copies on side streams ---- */
+/* ---- host-frame operator ---- */
 
 int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_bs *bs,
                            const hevcdbk_qp *qp, const hevcdbk_tables *tables, hevcdbk_timing *timing)

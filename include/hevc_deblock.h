@@ -130,9 +130,12 @@ typedef struct {
 /*
  * THE operator.  Replaces ReadYuvFrame::DeblockingFilter (cpu.h:134) and the body of ExecuteGpu
  * (gpu.cu:1246-1300: 7 H2D copies, 3 kernel launches, sync, 3 D2H copies) for a frame in HOST
- * memory, in place.  Staging goes through the context's pinned buffers with hipMemcpyAsync on
- * side streams; planes of a large frame that already lie in page-locked memory
- * (hevcdbk_host_malloc_pinned) are DMA'd where they lie instead.  bs / tables / timing may be NULL.
+ * memory, in place.  Frames up to 2 MiB: the fused Y+U+V kernel works on page-locked memory across the
+ * link itself.  Larger frames are cut into strips of whole block rows: on a large-BAR device the
+ * context's crew of host threads writes the strips into HBM through the BAR while the kernels of
+ * earlier strips store their results into page-locked memory (the caller's own planes where those
+ * are page-locked / registered with tight rows); elsewhere: pinned staging + hipMemcpyAsync on side
+ * streams.  See hevcdbk_set_host_threads / hevcdbk_host_register below.  bs / tables / timing may be NULL.
  */
 HEVCDBK_API int hevc_deblocking_filter(hevcdbk_context *ctx, hevcdbk_frame *frame, const hevcdbk_bs *bs,
                            const hevcdbk_qp *qp, const hevcdbk_tables *tables,
