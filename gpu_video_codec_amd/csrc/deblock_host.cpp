@@ -16,6 +16,7 @@
 
 #include <fcntl.h>
 #include <sched.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -456,6 +457,20 @@ uint8_t *push_buffer(hevcdbk_context *ctx, size_t bytes)
             (void)hipGetLastError();
             ctx->dev_push.p = nullptr;
             return nullptr;
+        }
+        /* "large BAR" says the card's memory CAN be mapped for the host; before the crew stores through the pointer, make sure THIS
+         * allocation is mapped into the process (msync fails with ENOMEM on an address range that has no mapping) -- a store to
+         * an unmapped address would be a SIGSEGV in the caller's process, the DMA path a few hundred microseconds */
+        {
+            const long pg = sysconf(_SC_PAGESIZE);
+            const uintptr_t a0 = (uintptr_t)ctx->dev_push.p & ~(uintptr_t)(pg - 1);
+            const uintptr_t a1 = ((uintptr_t)ctx->dev_push.p + bytes - 1) & ~(uintptr_t)(pg - 1);
+            if (msync((void *)a0, (size_t)pg, MS_ASYNC) != 0 || msync((void *)a1, (size_t)pg, MS_ASYNC) != 0) {
+                (void)hipFree(ctx->dev_push.p);
+                ctx->dev_push.p = nullptr;
+                ctx->large_bar = 0; /* ring + DMA from here on */
+                return nullptr;
+            }
         }
         ctx->dev_push.cap = bytes;
     }
