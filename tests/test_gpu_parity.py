@@ -1169,3 +1169,32 @@ def test_probed_destination_pool(ctx, oracle):
             assert e.value.code == _lib.ERR_ARG
         pool.free()
         b.free()
+
+
+def test_large_host_frames_of_odd_shapes(ctx, oracle):
+    """The strip schedule of the large-frame host call on shapes far from a video frame: planes 8 .. 24 samples wide and a hundred
+    thousand rows tall, very wide and flat ones, a width that is not a multiple of 64, 8 and 10 bit, 4:2:0 -- the strips must tile
+    every plane exactly (whole block rows, nothing twice, nothing left out) and the result must equal the oracle, with the crew
+    and with the caller alone."""
+    from gpu_video_codec_amd import synth
+    try:
+        for (w, h, bd, chroma) in ((16, 163840, 8, False), (8, 300000, 8, False), (8192, 512, 8, False), (2000, 1200, 8, False),
+                                   (24, 90000, 10, False), (32, 70000, 8, True), (16384, 256, 10, False)):
+            pl = synth.blocky_yuv420(w, h, seed=w + h, bit_depth=bd) if chroma else (synth.blocky_plane(w, h, seed=w + h, bit_depth=bd),)
+            want = [oracle.filter_plane(p, 37, bit_depth=bd, is_chroma=k > 0, threads=8) for k, p in enumerate(pl)]
+            for threads in (4, 1):
+                ctx.set_host_threads(threads)
+                got = [p.copy() for p in pl]
+                ctx.filter_frame(*got, qp=37, bit_depth=bd)
+                for g, wnt in zip(got, want):
+                    assert np.array_equal(g, wnt), (w, h, bd, chroma, threads)
+                tr = ctx.last_frame_trace()
+                assert tr, (w, h)
+                for k, p in enumerate(pl):
+                    mine = [s for s in tr if s["plane"] == k]
+                    assert mine[0]["row_begin"] == 0 and mine[-1]["row_end"] == p.shape[0], (w, h, k)
+                    assert all(a["row_end"] == b["row_begin"] for a, b in zip(mine, mine[1:])), (w, h, k)
+                    assert all((s["row_begin"] + 4) % 8 == 0 for s in mine[1:]), (w, h, k)   # strips start on block rows: 8b - 4
+                    assert sum(s["bytes"] for s in mine) == p.nbytes
+    finally:
+        ctx.set_host_threads(0)
