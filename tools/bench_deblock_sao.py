@@ -18,7 +18,11 @@ def main():
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--mode", choices=["ref", "h265"], default="ref")
     ap.add_argument("--types", default="mix")
+    ap.add_argument("--diag", action="append", default=None,
+                    help="diagnostic library with these knobs (csrc/hevcdbk_diag.h), e.g. noswz; may be given several times: one result per knob set")
     a = ap.parse_args()
+    if a.diag is not None:
+        _lib.use_diagnostic_library(a.diag[0] or None)
     w, h, n = a.width, a.height, a.frames
     ctx = deblock.Context(0)
     b = deblock.DeviceBatch(ctx, w, h, n, per_frame_bs=False)
@@ -51,7 +55,14 @@ def main():
 
     nbytes = 2 * n * w * h
     out = {}
-    for name, fused in (("fused", _lib.FUSED_ON), ("two_launches", _lib.FUSED_OFF), ("fused_again", _lib.FUSED_ON)):
+    runs = [("fused", _lib.FUSED_ON, None), ("two_launches", _lib.FUSED_OFF, None), ("fused_again", _lib.FUSED_ON, None)]
+    if a.diag is not None:
+        runs = [("fused[%s]" % k, _lib.FUSED_ON, k) for k in a.diag] * 2
+    for name, fused, knobs in runs:
+        if knobs is not None:
+            _lib.use_diagnostic_library(knobs or None)
+            if name in out:
+                name += " again"
         for _ in range(max(a.steps, 100)):
             call(fused)
         ctx.synchronize()
