@@ -196,6 +196,7 @@ int planes_to_args(const hevcdbk_device_planes *p, unsigned qp, const hevcdbk_ta
     a.vert_bs_stride = (long long)p->vert_bs_stride;
     a.hor_bs_stride = (long long)p->hor_bs_stride;
     if (p->qp_map && (p->ctu_log2 < 3 || p->ctu_log2 > 8)) return HEVCDBK_ERR_ARG; /* as the host-frame operator: units of 8 .. 256 luma samples */
+    if (p->qp_map && p->qp_map_stride >= (1u << 24)) return HEVCDBK_ERR_UNSUPPORTED; /* the kernels index the map with 24-bit multiplies */
     a.qp_map = p->qp_map;
     a.map_stride = (int)p->qp_map_stride;
     a.ctu_log2 = (int)p->ctu_log2;

@@ -257,18 +257,17 @@ __device__ __forceinline__ void load_bs_buffer_h265(const DbkArgs &a, int f, int
 /* per-segment tc / beta of a lane's block: the scalar-QP values, or -- QPMAP -- looked up from the per-CTU
  * map exactly as the generic kernel and the oracle do (QP = (QpP + QpQ + 1) >> 1 of the CTUs holding P0 / Q0
  * of the segment's first line) */
+template <bool CHROMA>
+__device__ __forceinline__ void block_unit_qps_dev(const DbkArgs &a, int f, int by, int bx, int (&u)[4]);
 template <bool QPMAP, bool CHROMA>
 __device__ __forceinline__ dbk::BlockQp block_qp(const DbkArgs &a, int f, int by, int bx)
 {
     dbk::BlockQp q;
     if constexpr (QPMAP) {
-        const uint8_t *map = a.qp_map + (long long)f * a.map_frame_stride;
-        const int sc = CHROMA ? 2 : 1, lw = a.plane_w * sc, lh = a.plane_h * sc;
-        const int x0 = bx * 8 - 4, y0 = by * 8 - 4;
         /* the generic kernel's eight look-ups (seg_qp_from_map per segment) are four map units: above-left, above-right,
          * below-left, below-right of the block's centre (block_unit_qps); hor2 pairs above-right with below-LEFT (cpu.h:383-414) */
         int u[4];
-        dbk::block_unit_qps(map, a.map_stride, a.ctu_log2, sc, lw, lh, x0, y0, u);
+        block_unit_qps_dev<CHROMA>(a, f, by, bx, u);
         const int qp0 = dbk::seg_qp_avg(u[0], u[1]), qp1 = dbk::seg_qp_avg(u[2], u[3]);
         const int qp2 = dbk::seg_qp_avg(u[0], u[2]), qp3 = dbk::seg_qp_avg(u[1], u[2]);
         q.tc[0] = a.tc_tab[qp0] << a.shift; q.beta[0] = a.beta_tab[qp0] << a.shift;
@@ -284,13 +283,43 @@ __device__ __forceinline__ dbk::BlockQp block_qp(const DbkArgs &a, int f, int by
 
 /* QP-map launches, luma (round 4): the segments' QPs as INDICES into the workgroup's operand table instead of tc / beta values
  * (reference-exact mode: one index serves both halves of the table) */
+/* The four map units of a lane's block (dbk::block_unit_qps, deblock_core.h: above-left, above-right, below-left, below-right of
+ * the block's centre) through a buffer resource: 32-bit offsets from ONE 24-bit multiply-add (map rows and strides are far below
+ * 2^24: the entry points check the stride) instead of two 32 x 32-bit multiplies -- quarter rate on this hardware -- and four
+ * 64-bit address sums.  Same clamping, same values. */
+template <bool CHROMA>
+__device__ __forceinline__ void block_unit_qps_dev(const DbkArgs &a, int f, int by, int bx, int (&u)[4])
+{
+    const int sc = CHROMA ? 2 : 1, lw = a.plane_w * sc, lh = a.plane_h * sc;
+    const int x0 = bx * 8 - 4, y0 = by * 8 - 4;
+    const int xl = dbk::clampi((x0 + 3) * sc, 0, lw - 1) >> a.ctu_log2, xr = dbk::clampi((x0 + 4) * sc, 0, lw - 1) >> a.ctu_log2;
+    const int yt = dbk::clampi((y0 + 3) * sc, 0, lh - 1) >> a.ctu_log2, yb = dbk::clampi((y0 + 4) * sc, 0, lh - 1) >> a.ctu_log2;
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.qp_map) + (long long)f * a.map_frame_stride, 0, 0x80000000u, 0x00020000);
+    const uint32_t ot = __umul24((uint32_t)yt, (uint32_t)a.map_stride);
+    const uint32_t ob = yb != yt ? ot + (uint32_t)a.map_stride : ot; /* the lower unit row is the same one or the next */
+    u[0] = __builtin_amdgcn_raw_buffer_load_b8(rm, ot + (uint32_t)xl, 0, 0);
+    u[1] = __builtin_amdgcn_raw_buffer_load_b8(rm, ot + (uint32_t)xr, 0, 0);
+    u[2] = __builtin_amdgcn_raw_buffer_load_b8(rm, ob + (uint32_t)xl, 0, 0);
+    u[3] = __builtin_amdgcn_raw_buffer_load_b8(rm, ob + (uint32_t)xr, 0, 0);
+}
+/* the spec-exact mode's four segment QPs from them (dbk::h265_block_qpl4) */
+template <bool CHROMA>
+__device__ __forceinline__ void block_qpl4_dev(const DbkArgs &a, int f, int by, int bx, int (&qpl)[4])
+{
+    int q[4];
+    block_unit_qps_dev<CHROMA>(a, f, by, bx, q);
+    qpl[0] = dbk::seg_qp_avg(q[0], q[1]); /* ver1: above-left | above-right */
+    qpl[1] = dbk::seg_qp_avg(q[2], q[3]); /* ver2: below-left | below-right */
+    qpl[2] = dbk::seg_qp_avg(q[0], q[2]); /* hor1: above-left / below-left */
+    qpl[3] = dbk::seg_qp_avg(q[1], q[3]); /* hor2: above-right / below-right */
+}
+
 template <bool CHROMA>
 __device__ __forceinline__ dbk::QsTable block_qp_tab(const DbkArgs &a, int f, int by, int bx, const DBK_LDS uint32_t *tab)
 {
-    const uint8_t *map = a.qp_map + (long long)f * a.map_frame_stride;
-    const int sc = CHROMA ? 2 : 1, lw = a.plane_w * sc, lh = a.plane_h * sc;
     int u[4];
-    dbk::block_unit_qps(map, a.map_stride, a.ctu_log2, sc, lw, lh, bx * 8 - 4, by * 8 - 4, u);
+    block_unit_qps_dev<CHROMA>(a, f, by, bx, u);
     dbk::QsTable q;
     q.tab = tab;
     q.ib[0] = q.it[0] = dbk::seg_qp_avg(u[0], u[1]);
@@ -508,9 +537,7 @@ __device__ __forceinline__ void packed_body(const DbkArgs &a, int by, int f, int
         dbk::H265Seg sg;
         if constexpr (QPMAP) {
             int qpl[4];
-            const int sc = CHROMA ? 2 : 1, bxa = active ? bx : 0;
-            dbk::h265_block_qpl4(a.qp_map + (long long)f * a.map_frame_stride, a.map_stride, a.ctu_log2, sc, a.plane_w * sc,
-                                 a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, qpl);
+            block_qpl4_dev<CHROMA>(a, f, by, active ? bx : 0, qpl);
             const dbk::H265Prm prm = {hx->tc_off, hx->beta_off, hx->c_qp_offset, 0, 255};
             if constexpr (KT) {
                 if constexpr (PATH != 3) ktab = ktab_setup_h265(ktab_lds, 0);
@@ -667,9 +694,7 @@ __device__ __forceinline__ void packed16_body(const DbkArgs &a, int by, int f, i
         dbk::H265Seg sg;
         if constexpr (QPMAP) {
             int qpl[4];
-            const int sc = CHROMA ? 2 : 1, bxa = active ? bx : 0;
-            dbk::h265_block_qpl4(a.qp_map + (long long)f * a.map_frame_stride, a.map_stride, a.ctu_log2, sc, a.plane_w * sc,
-                                 a.plane_h * sc, bxa * 8 - 4, by * 8 - 4, qpl);
+            block_qpl4_dev<CHROMA>(a, f, by, active ? bx : 0, qpl);
             const dbk::H265Prm prm = {hx->tc_off, hx->beta_off, hx->c_qp_offset, a.shift, a.max_v};
             if constexpr (KT) dbk::h265_seg_rows(entry, qpl, prm, ktab_setup_h265(ktab_lds, a.shift), sg);
             else dbk::h265_seg_params<CHROMA>(entry, qpl, prm, sg);

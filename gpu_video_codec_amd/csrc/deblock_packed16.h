@@ -95,8 +95,9 @@ DBK_HD void packed_filter_luma_block16_h265(uint32_t (&W)[8][4], const H265Seg &
 {
     Taps va1 = unpack_ver16(W[0], W[3]), vb1 = unpack_ver16(W[1], W[2]);
     Taps va2 = unpack_ver16(W[4], W[7]), vb2 = unpack_ver16(W[5], W[6]);
-    luma_seg_h265<WIDE, TAB>(va1, vb1, s, 0, max_v, u);
-    luma_seg_h265<WIDE, TAB>(va2, vb2, s, 1, max_v, u);
+    const bool keep_any = h265_keep_any(s);
+    luma_seg_h265<WIDE, TAB>(va1, vb1, s, 0, max_v, u, keep_any);
+    luma_seg_h265<WIDE, TAB>(va2, vb2, s, 1, max_v, u, keep_any);
     Taps ha, hb, ga, gb;
     ha.p0 = pick_hi(va1.p3, va1.p0); hb.p0 = pick_hi(va1.p2, va1.p1);
     ha.p1 = pick_hi(vb1.p3, vb1.p0); hb.p1 = pick_hi(vb1.p2, vb1.p1);
@@ -106,7 +107,7 @@ DBK_HD void packed_filter_luma_block16_h265(uint32_t (&W)[8][4], const H265Seg &
     ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1);
     ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1);
     ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1);
-    luma_seg_h265<WIDE, TAB>(ha, hb, s, 2, max_v, u);
+    luma_seg_h265<WIDE, TAB>(ha, hb, s, 2, max_v, u, keep_any);
     ga.p0 = pick_hi(va1.q0, va1.q3); gb.p0 = pick_hi(va1.q1, va1.q2);
     ga.p1 = pick_hi(vb1.q0, vb1.q3); gb.p1 = pick_hi(vb1.q1, vb1.q2);
     ga.p2 = pick_lo(vb1.q0, vb1.q3); gb.p2 = pick_lo(vb1.q1, vb1.q2);
@@ -115,7 +116,7 @@ DBK_HD void packed_filter_luma_block16_h265(uint32_t (&W)[8][4], const H265Seg &
     ga.q1 = pick_lo(vb2.q0, vb2.q3); gb.q1 = pick_lo(vb2.q1, vb2.q2);
     ga.q2 = pick_hi(vb2.q0, vb2.q3); gb.q2 = pick_hi(vb2.q1, vb2.q2);
     ga.q3 = pick_hi(va2.q0, va2.q3); gb.q3 = pick_hi(va2.q1, va2.q2);
-    luma_seg_h265<WIDE, TAB>(ga, gb, s, 3, max_v, u);
+    luma_seg_h265<WIDE, TAB>(ga, gb, s, 3, max_v, u, keep_any);
     /* pair A = cols (0,3) / (4,7), pair B = cols (1,2) / (5,6):  (c0,c1) = (A.lo,B.lo), (c2,c3) = (B.hi,A.hi) */
 #define DBK_ROW16H(r, A, B, j)            \
     W[r][j] = pk_bits(pick_lo(A, B));      \

@@ -131,13 +131,19 @@ DBK_HD bool opaque_uniform(bool v)
 #endif
 }
 
+/* keep_any (wave-uniform, once per block: h265_keep_any): some lane of the wave carries a keep flag in one of its four
+ * segments.  PCM / transquant-bypass units are rare, so nearly every wave skips the keep-flag tests of all four segments on one
+ * scalar branch each instead of evaluating them per lane. */
 template <bool WIDE = false>
-DBK_HD void luma_pairs_h265_uni(Taps &a, Taps &b, int entry, int beta, int tc, int max_v, const H265Uni &u)
+DBK_HD void luma_pairs_h265_uni(Taps &a, Taps &b, int entry, int beta, int tc, int max_v, const H265Uni &u, bool keep_any)
 {
     const int bs = entry & kH265BsMask;
-    const bool keep = (entry & (kH265KeepP | kH265KeepQ)) != 0;
-    if (any_lane(bs != 0 && keep)) luma_pairs_h265<WIDE>(a, b, keep ? entry : 0, beta, tc, max_v); /* entry 0: lane off */
-    const bool fast = bs != 0 && !keep;
+    bool fast = bs != 0;
+    if (keep_any) {
+        const bool keep = (entry & (kH265KeepP | kH265KeepQ)) != 0;
+        if (any_lane(bs != 0 && keep)) luma_pairs_h265<WIDE>(a, b, keep ? entry : 0, beta, tc, max_v); /* entry 0: lane off */
+        fast = fast && !keep;
+    }
     const unsigned long long m1 = lane_ballot(fast && bs == 1), m2 = lane_ballot(fast && bs == 2);
 #if DBK_DEV
     const bool one_bs = m1 == 0ull || m2 == 0ull;
@@ -163,12 +169,15 @@ DBK_HD void luma_pairs_h265_uni(Taps &a, Taps &b, int entry, int beta, int tc, i
  * lane without a keep flag, the general form for the others -- two stages, as above.
  */
 template <bool WIDE = false>
-DBK_HD void luma_pairs_h265_map(Taps &a, Taps &b, int entry, int beta, int tc, int max_v)
+DBK_HD void luma_pairs_h265_map(Taps &a, Taps &b, int entry, int beta, int tc, int max_v, bool keep_any)
 {
     const int bs = entry & kH265BsMask;
-    const bool keep = (entry & (kH265KeepP | kH265KeepQ)) != 0;
-    if (any_lane(bs != 0 && keep)) luma_pairs_h265<WIDE>(a, b, keep ? entry : 0, beta, tc, max_v);
-    const bool fast = bs != 0 && !keep;
+    bool fast = bs != 0;
+    if (keep_any) {
+        const bool keep = (entry & (kH265KeepP | kH265KeepQ)) != 0;
+        if (any_lane(bs != 0 && keep)) luma_pairs_h265<WIDE>(a, b, keep ? entry : 0, beta, tc, max_v);
+        fast = fast && !keep;
+    }
     if (any_lane(fast)) luma_pairs<WIDE, false>(a, b, LumaKEager::make<true>(beta, tc), max_v, 0, fast);
 }
 
@@ -176,12 +185,15 @@ DBK_HD void luma_pairs_h265_map(Taps &a, Taps &b, int entry, int beta, int tc, i
  * qPL + beta_offset and the tc index qPL + 2 (bS - 1) + tc_offset, round 4): no beta / tc values are looked up at all unless
  * a lane of the wave carries a keep flag. */
 template <bool WIDE = false>
-DBK_HD void luma_pairs_h265_tab(Taps &a, Taps &b, int entry, const DBK_LDS uint32_t *tab, int ib, int it, int shift, int max_v)
+DBK_HD void luma_pairs_h265_tab(Taps &a, Taps &b, int entry, const DBK_LDS uint32_t *tab, int ib, int it, int shift, int max_v, bool keep_any)
 {
     const int bs = entry & kH265BsMask;
-    const bool keep = (entry & (kH265KeepP | kH265KeepQ)) != 0;
-    if (any_lane(bs != 0 && keep)) luma_pairs_h265<WIDE>(a, b, keep ? entry : 0, h265_beta(ib) << shift, h265_tc(it) << shift, max_v);
-    const bool fast = bs != 0 && !keep;
+    bool fast = bs != 0;
+    if (keep_any) {
+        const bool keep = (entry & (kH265KeepP | kH265KeepQ)) != 0;
+        if (any_lane(bs != 0 && keep)) luma_pairs_h265<WIDE>(a, b, keep ? entry : 0, h265_beta(ib) << shift, h265_tc(it) << shift, max_v);
+        fast = fast && !keep;
+    }
     if (any_lane(fast)) luma_pairs<WIDE, false>(a, b, LumaKLds::rows(tab, ib, it), max_v, 0, fast);
 }
 
@@ -224,14 +236,19 @@ struct H265Seg {
     int ib[4], it[4], shift;
 };
 /* a segment of a one-QP kernel (u != NULL) or of a QP-map kernel (TAB: operands from the workgroup's table) */
+/* one test for the block's four segments (see luma_pairs_h265_uni) */
+DBK_HD bool h265_keep_any(const H265Seg &s)
+{
+    return any_lane(((s.entry[0] | s.entry[1] | s.entry[2] | s.entry[3]) & (int)(kH265KeepP | kH265KeepQ)) != 0);
+}
 template <bool WIDE = false, bool TAB = false>
-DBK_HD void luma_seg_h265(Taps &a, Taps &b, const H265Seg &s, int i, int max_v, const H265Uni *u)
+DBK_HD void luma_seg_h265(Taps &a, Taps &b, const H265Seg &s, int i, int max_v, const H265Uni *u, bool keep_any)
 {
     if constexpr (TAB) {
-        luma_pairs_h265_tab<WIDE>(a, b, s.entry[i], s.tab, s.ib[i], s.it[i], s.shift, max_v);
+        luma_pairs_h265_tab<WIDE>(a, b, s.entry[i], s.tab, s.ib[i], s.it[i], s.shift, max_v, keep_any);
     } else {
-        if (u) luma_pairs_h265_uni<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v, *u);
-        else luma_pairs_h265_map<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v);
+        if (u) luma_pairs_h265_uni<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v, *u, keep_any);
+        else luma_pairs_h265_map<WIDE>(a, b, s.entry[i], s.beta[i], s.tc[i], max_v, keep_any);
     }
 }
 
@@ -241,8 +258,9 @@ DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], co
 {
     Taps va1 = unpack_ver(L[0], L[3], R[0], R[3]), vb1 = unpack_ver(L[1], L[2], R[1], R[2]);
     Taps va2 = unpack_ver(L[4], L[7], R[4], R[7]), vb2 = unpack_ver(L[5], L[6], R[5], R[6]);
-    luma_seg_h265<false, TAB>(va1, vb1, s, 0, 255, u);
-    luma_seg_h265<false, TAB>(va2, vb2, s, 1, 255, u);
+    const bool keep_any = h265_keep_any(s);
+    luma_seg_h265<false, TAB>(va1, vb1, s, 0, 255, u, keep_any);
+    luma_seg_h265<false, TAB>(va2, vb2, s, 1, 255, u, keep_any);
 
     Taps ha, hb, ga, gb;
     /* hor1: lines = cols 0..3 (ver taps p3..p0), P_k = row 3-k, Q_k = row 4+k */
@@ -254,7 +272,7 @@ DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], co
     ha.q1 = pick_lo(vb2.p3, vb2.p0); hb.q1 = pick_lo(vb2.p2, vb2.p1);
     ha.q2 = pick_hi(vb2.p3, vb2.p0); hb.q2 = pick_hi(vb2.p2, vb2.p1);
     ha.q3 = pick_hi(va2.p3, va2.p0); hb.q3 = pick_hi(va2.p2, va2.p1);
-    luma_seg_h265<false, TAB>(ha, hb, s, 2, 255, u);
+    luma_seg_h265<false, TAB>(ha, hb, s, 2, 255, u, keep_any);
     /* hor2: lines = cols 4..7 (ver taps q0..q3), same rows */
     ga.p0 = pick_hi(va1.q0, va1.q3); gb.p0 = pick_hi(va1.q1, va1.q2);
     ga.p1 = pick_hi(vb1.q0, vb1.q3); gb.p1 = pick_hi(vb1.q1, vb1.q2);
@@ -264,7 +282,7 @@ DBK_HD void packed_filter_luma_block_h265(uint32_t (&L)[8], uint32_t (&R)[8], co
     ga.q1 = pick_lo(vb2.q0, vb2.q3); gb.q1 = pick_lo(vb2.q1, vb2.q2);
     ga.q2 = pick_hi(vb2.q0, vb2.q3); gb.q2 = pick_hi(vb2.q1, vb2.q2);
     ga.q3 = pick_hi(va2.q0, va2.q3); gb.q3 = pick_hi(va2.q1, va2.q2);
-    luma_seg_h265<false, TAB>(ga, gb, s, 3, 255, u);
+    luma_seg_h265<false, TAB>(ga, gb, s, 3, 255, u, keep_any);
 
     L[0] = row_of(ha.p3, hb.p3); L[1] = row_of(ha.p2, hb.p2); L[2] = row_of(ha.p1, hb.p1); L[3] = row_of(ha.p0, hb.p0);
     L[4] = row_of(ha.q0, hb.q0); L[5] = row_of(ha.q1, hb.q1); L[6] = row_of(ha.q2, hb.q2); L[7] = row_of(ha.q3, hb.q3);

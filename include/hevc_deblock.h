@@ -214,7 +214,7 @@ typedef struct {
     const uint8_t *hor_bs;
     size_t vert_bs_stride, hor_bs_stride;
     const uint8_t *qp_map; /* DEVICE or NULL; frame f at qp_map + f*qp_map_frame_stride */
-    unsigned qp_map_stride, ctu_log2; /* entries per map row; log2 of the map unit in luma samples, 3 .. 8 (HEVCDBK_ERR_ARG otherwise) */
+    unsigned qp_map_stride, ctu_log2; /* entries per map row (< 2^24, HEVCDBK_ERR_UNSUPPORTED otherwise); log2 of the map unit in luma samples, 3 .. 8 (HEVCDBK_ERR_ARG otherwise) */
     size_t qp_map_frame_stride;
 } hevcdbk_device_planes;
 
