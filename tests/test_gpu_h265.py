@@ -249,6 +249,47 @@ def test_sao_on_device(ctx, h265):
     b.free()
 
 
+def test_sao_edge_offset_pictures(ctx, h265):
+    """Pictures in which EVERY CTB runs the edge offset: each class on its own (all aligned pairs take the wide wave shape), a
+    class per CTB (narrow waves), a class per aligned pair (wide waves of different classes side by side), widths that leave a
+    single CTB or a partial one at the right edge, with and without keep flags -- the wave shapes of sao8_kernel one by one
+    (written for a form that took the halo from neighbouring lanes by DPP: bit-exact, 8 % slower, not kept)."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    rng = np.random.RandomState(77)
+    for (w, h) in [(1920, 1088), (1984, 576), (200, 136)]:
+        frames = np.stack([synth.blocky_plane(w, h, seed=w + i) for i in range(2)])
+        frames = np.clip(frames.astype(np.int32) + rng.randint(-4, 5, frames.shape), 0, 255).astype(np.uint8)
+        rows, cols = (h + 63) // 64, (w + 63) // 64
+        for case in ("cls0", "cls1", "cls2", "cls3", "per_ctb", "pairs"):
+            prm = np.zeros((2, rows, cols), np.dtype(_lib.SAO_CTB_DTYPE))
+            prm["type"] = 2
+            if case.startswith("cls"):
+                prm["cls"] = int(case[3])
+            elif case == "per_ctb":
+                prm["cls"] = rng.randint(0, 4, prm.shape)
+            else:  # the same class in both CTBs of every aligned pair, another one in the next pair
+                pc = rng.randint(0, 4, (2, rows, (cols + 1) // 2))
+                prm["cls"] = np.repeat(pc, 2, axis=2)[:, :, :cols]
+            prm["offset"] = rng.randint(-7, 8, prm.shape + (4,))
+            keep = (rng.randint(0, 40, (2, h // 8, w // 8)) == 0).astype(np.uint8)
+            b = deblock.DeviceBatch(ctx, w, h, 2, per_frame_bs=False)
+            b.upload_all(frames, fill=0x5A)
+            dp, dk = ctx.alloc(prm.nbytes), ctx.alloc(keep.nbytes)
+            dp.upload(prm.view(np.uint8).ravel())
+            dk.upload(keep.ravel())
+            for use_keep in (False, True):
+                ctx.sao_device(b.planes(), dp.ptr, cols, 6, params_frame_stride=rows * cols,
+                               keep_ptr=dk.ptr if use_keep else None, keep_stride=w // 8, keep_frame_stride=(h // 8) * (w // 8))
+                ctx.synchronize()
+                for f in range(2):
+                    want = h265.sao_plane(frames[f], prm[f], 6, bit_depth=8, keep=keep[f] if use_keep else None)
+                    assert np.array_equal(b.download_frame(f), want), (w, h, case, use_keep, f)
+                assert (want != frames[1]).any()
+            dp.free()
+            dk.free()
+            b.free()
+
+
 def test_deblock_sao_one_call(ctx, h265, oracle):
     """hevc_deblock_sao_device / hevc_deblock_sao_h265_device: deblocking followed by SAO, src -> dst, as ONE kernel (a
     workgroup deblocks the offset blocks of a 192 x 128 tile into LDS and applies SAO from there) and as two launches through
