@@ -39,8 +39,8 @@ for m in 6 4 3; do python3 "$R/tools/bench_qpmap.py" --qp-map $m --bs lcg >> "$O
 python3 "$R/tools/bench_qpmap.py" --qp-map 0 --bs lcg >> "$OUT/bench_qpmap.json"
 python3 "$R/tools/bench_h265.py" --only packed --qp-map 4 --bs mixed > "$OUT/bench_h265_qpmap.json" 2>/dev/null || true
 python3 "$R/tools/bench_h265.py" --only packed --qp-map 6 --bs mixed >> "$OUT/bench_h265_qpmap.json" 2>/dev/null || true
-python3 "$R/tools/exp/sq_any.py" --kernel dbk_packed_kernel --tag r04_ref_qpmap tools/bench_qpmap.py --steps 5 --qp-map 6 > "$OUT/sq_ref_qpmap.log" 2>&1 || true
-python3 "$R/tools/exp/sq_any.py" --kernel dbk_packed_kernel --tag r04_ref_one_qp tools/bench_qpmap.py --steps 5 --qp-map 0 > "$OUT/sq_ref_one_qp.log" 2>&1 || true
-python3 "$R/tools/exp/sq_any.py" --kernel dbk_packed_h265_kernel --tag r04_h265_qpmap tools/bench_h265.py --steps 5 --qp-map 4 --bs mixed --only packed > "$OUT/sq_h265_qpmap.log" 2>&1 || true
+python3 "$R/tools/sq_of.py" --kernel dbk_packed_kernel --tag r04_ref_qpmap --more -- tools/bench_qpmap.py --steps 5 --qp-map 6 > "$OUT/sq_ref_qpmap.log" 2>&1 || true
+python3 "$R/tools/sq_of.py" --kernel dbk_packed_kernel --tag r04_ref_one_qp --more -- tools/bench_qpmap.py --steps 5 --qp-map 0 > "$OUT/sq_ref_one_qp.log" 2>&1 || true
+python3 "$R/tools/sq_of.py" --kernel dbk_packed_h265_kernel --tag r04_h265_qpmap --more -- tools/bench_h265.py --steps 5 --qp-map 4 --bs mixed --only packed > "$OUT/sq_h265_qpmap.log" 2>&1 || true
 cp "$R"/gpurun_out/sq/r04_*.json "$OUT/" 2>/dev/null || true
 echo done
