@@ -1425,6 +1425,9 @@ hipError_t dbk_launch_deblock_sao(const DbkArgs &d, const DbkSaoArgs &s, int sam
     if (d.n_frames <= 0 || d.nbx <= 0 || d.nby <= 0) return hipSuccess;
     DbkFusedArgs fa;
     fa.d = d;
+#ifdef HEVCDBK_DIAG
+    fa.d.diag_prio = g_dbk_diag.prio; /* wave priority experiment of the fused kernel (deblock_sao_fused.inc) */
+#endif
     fa.s = s;
     const bool qm = d.qp_map != nullptr;
     const dim3 grid(fused_grid(d.plane_w, d.plane_h, d.n_frames, sample_bytes, fa.g), 1, 1);

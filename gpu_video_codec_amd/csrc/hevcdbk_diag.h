@@ -40,7 +40,8 @@ extern "C" {
  *   queue     8-bit luma through the LDS-queue kernel (bit-exact, slower)
  *   align     copy variant: row spans shifted onto their natural alignment
  *   mode3     8-bit luma through the instrumented instantiation of the kernel with no knob active (A/B baseline)
- *   prio=N    wave priority experiment: bit 0 = s_setprio 3 until the row loads are issued, bit 1 = from the final pack on
+ *   prio=N    wave priority experiment: bit 0 = s_setprio 3 until the row loads are issued, bit 1 = from the final pack on (8-bit
+ *             fused deblocking + SAO kernel: bit 1 = s_setprio 2 behind the barrier, for the whole of stage 2)
  *   dummy=N   N extra VALU instructions per wave (how the kernel time responds to VALU work); with the stripe map
  *             a bit set of timing experiments instead: 1 no bS DMA, 2 no stores, 4 no tile DMA, 8 no border,
  *             16 a workgroup barrier before the stores; with the plain maps' copy variant: 32 = lane pairs move their
