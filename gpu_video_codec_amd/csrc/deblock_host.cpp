@@ -242,7 +242,7 @@ int launch(hevcdbk_context *ctx, const DbkArgs &a0, int sample_bytes, bool chrom
 /* hevcdbk_diag.h: the knobs of the diagnostic library (never compiled into libhevcdbk.so) */
 extern "C" HEVCDBK_API int hevcdbk_diag_set(const char *spec)
 {
-    DbkDiag d = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    DbkDiag d = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const std::string sp = spec ? spec : "";
     size_t i = 0;
     while (i < sp.size()) {
@@ -264,6 +264,7 @@ extern "C" HEVCDBK_API int hevcdbk_diag_set(const char *spec)
         else if (tok.compare(0, 6, "dummy=") == 0) d.dummy = std::atoi(tok.c_str() + 6);
         else if (tok.compare(0, 5, "rows=") == 0) d.rows = std::atoi(tok.c_str() + 5);
         else if (tok.compare(0, 4, "lds=") == 0) d.lds = std::atoi(tok.c_str() + 4);
+        else if (tok.compare(0, 5, "xpad=") == 0) d.xpad = std::atoi(tok.c_str() + 5);
         else if (tok.compare(0, 3, "wg=") == 0) {
             const int c = std::atoi(tok.c_str() + 3) / 64 * 64;
             if (c < 64 || c > 1024) return HEVCDBK_ERR_ARG;

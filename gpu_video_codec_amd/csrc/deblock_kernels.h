@@ -99,6 +99,7 @@ struct DbkDiag {
     int mode3;     /* run the instrumented (MODE 3) instantiation even with no ablation set: the A/B baseline */
     int rows;      /* pipe map: block rows per workgroup (default 4) */
     int lds;       /* dynamic LDS bytes per workgroup of the plain packed kernels: an occupancy limiter for A/B runs */
+    int xpad;      /* row-major map: N padding workgroups per XCD range (the XCDs' fronts move out of step with each other) */
 };
 extern DbkDiag g_dbk_diag;
 #endif

@@ -979,7 +979,7 @@ bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
 }
 
 #ifdef HEVCDBK_DIAG
-DbkDiag g_dbk_diag = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+DbkDiag g_dbk_diag = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static int wg_cap() { return g_dbk_diag.wg_cap; }
 #else
 /* workgroup width cap of the packed kernels (measured best on MI355X; the diagnostic build can vary it) */
@@ -1061,6 +1061,9 @@ static bool plan_packed(const DbkArgs &a, DbkArgs &b, dim3 &grid, dim3 &block)
         b.magic_nbx = (uint32_t)((1ull << 32) / (unsigned long long)a.nbx + 1ull);
         block = dim3(wg, 1, 1);
         grid = dim3((unsigned)total, 1, 1);
+#ifdef HEVCDBK_DIAG
+        if (g_dbk_diag.xpad > 0 && b.xcd_swizzle) grid = dim3((unsigned)(total + 8ll * g_dbk_diag.xpad), 1, 1); /* experiment: see DbkDiag::xpad */
+#endif
         return true;
     }
     /* small planes / degenerate divisors: one workgroup per block row, wider rows split into cap-lane chunks */

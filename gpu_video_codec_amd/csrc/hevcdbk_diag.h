@@ -49,6 +49,8 @@ extern "C" {
  *   rows=N    pipe map: block rows per workgroup (default 4)
  *   lds=N     N bytes of unused dynamic LDS per workgroup of the plain 8-bit luma kernel and its copy variant: limits the
  *             workgroups per CU (160 KiB / N) for occupancy A/B runs
+ *   xpad=N    row-major map of the packed kernels: N padding workgroups behind every XCD's range, so that the eight XCDs do not
+ *             walk through the batch at offsets that are equal modulo a power of two (placement experiments)
  *   nostrong | nonormal | barriers   luma ablations -- WRONG PIXELS, timing only
  * returns HEVCDBK_OK or HEVCDBK_ERR_ARG (unknown knob; nothing changed) */
 HEVCDBK_API int hevcdbk_diag_set(const char *spec);
