@@ -242,7 +242,7 @@ int launch(hevcdbk_context *ctx, const DbkArgs &a0, int sample_bytes, bool chrom
 /* hevcdbk_diag.h: the knobs of the diagnostic library (never compiled into libhevcdbk.so) */
 extern "C" HEVCDBK_API int hevcdbk_diag_set(const char *spec)
 {
-    DbkDiag d = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    DbkDiag d; /* the defaults of the struct */
     const std::string sp = spec ? spec : "";
     size_t i = 0;
     while (i < sp.size()) {

@@ -87,19 +87,19 @@ hipError_t dbk_launch_packed_multi(const DbkArgs *planes, int n, int sample_byte
 /* knobs of the diagnostic build, set through hevcdbk_diag_set() (hevcdbk_diag.h); the product library has none of this and
  * reads no environment variable */
 struct DbkDiag {
-    int wg_cap;    /* workgroup width cap of the packed kernels (64..1024), default 512 */
-    int noswz;     /* row-major map without the per-XCD renumbering */
-    int nofuse;    /* no fused Y+U+V launch */
-    int dmacopy;   /* small frames through DMA copies instead of host-direct kernels */
-    int ablate;    /* 1 nostrong, 2 nonormal, 4 barriers: WRONG pixels, timing only */
-    int queue;     /* the LDS-queue kernel for 8-bit luma */
-    int align;     /* copy mode: shift the row spans onto their natural alignment */
-    int prio;      /* wave priority experiment, see DbkArgs::diag_prio */
-    int dummy;     /* extra VALU instructions per wave */
-    int mode3;     /* run the instrumented (MODE 3) instantiation even with no ablation set: the A/B baseline */
-    int rows;      /* pipe map: block rows per workgroup (default 4) */
-    int lds;       /* dynamic LDS bytes per workgroup of the plain packed kernels: an occupancy limiter for A/B runs */
-    int xpad;      /* row-major map: N padding workgroups per XCD range (the XCDs' fronts move out of step with each other) */
+    int wg_cap = 512; /* workgroup width cap of the packed kernels (64..1024) */
+    int noswz = 0;     /* row-major map without the per-XCD renumbering */
+    int nofuse = 0;    /* no fused Y+U+V launch */
+    int dmacopy = 0;   /* small frames through DMA copies instead of host-direct kernels */
+    int ablate = 0;    /* 1 nostrong, 2 nonormal, 4 barriers: WRONG pixels, timing only */
+    int queue = 0;     /* the LDS-queue kernel for 8-bit luma */
+    int align = 0;     /* copy mode: shift the row spans onto their natural alignment */
+    int prio = 0;      /* wave priority experiment, see DbkArgs::diag_prio */
+    int dummy = 0;     /* extra VALU instructions per wave */
+    int mode3 = 0;     /* run the instrumented (MODE 3) instantiation even with no ablation set: the A/B baseline */
+    int rows = 0;      /* pipe map: block rows per workgroup (default 4) */
+    int lds = 0;       /* dynamic LDS bytes per workgroup of the plain packed kernels: an occupancy limiter for A/B runs */
+    int xpad = 0;      /* row-major map: N padding workgroups per XCD range (the XCDs' fronts move out of step with each other) */
 };
 extern DbkDiag g_dbk_diag;
 #endif

@@ -979,7 +979,7 @@ bool dbk_packed_supports(const DbkArgs &a, int sample_bytes, bool chroma)
 }
 
 #ifdef HEVCDBK_DIAG
-DbkDiag g_dbk_diag = {512, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+DbkDiag g_dbk_diag; /* the defaults of the struct */
 static int wg_cap() { return g_dbk_diag.wg_cap; }
 #else
 /* workgroup width cap of the packed kernels (measured best on MI355X; the diagnostic build can vary it) */
