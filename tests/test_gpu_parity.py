@@ -246,6 +246,49 @@ def test_qp_map_with_lane_varying_tc_on_flat_content(ctx, oracle):
             b.free()
 
 
+def test_qp_map_regions_equal_scalar_launches_at_4k(ctx):
+    """A size-independent property at BASELINE's frame size that ties the QP-map kernels to the scalar-QP kernels (which the
+    reference-made hashes pin): with a map that is constant over the four quadrants of a 3840x2160 picture, every sample further
+    than 8 samples from a quadrant border must come out exactly as a launch with that quadrant's ONE QP makes it (no decision
+    that reaches it sees another QP: tests/test_oracle.py measures 4 samples) -- 64- and 16-sample units, default and seeded bS,
+    8 and 10 bit, packed and generic kernels."""
+    from gpu_video_codec_amd import deblock, synth, _lib
+    w, h = 3840, 2160
+    rng = np.random.RandomState(5)
+    for (bd, log2, variant, seeded) in ((8, 6, _lib.KERNEL_AUTO, False), (8, 4, _lib.KERNEL_PACKED, True), (10, 6, _lib.KERNEL_AUTO, True),
+                                        (8, 6, _lib.KERNEL_GENERIC, True)):
+        unit = 1 << log2
+        rows, cols = (h + unit - 1) // unit, (w + unit - 1) // unit
+        by, bx = (rows // 2) * unit, (cols // 2) * unit
+        qps = {(0, 0): 27, (0, 1): 39, (1, 0): 46, (1, 1): 33}
+        qmap = np.zeros((rows, cols), np.uint8)
+        for (ry, rx), q in qps.items():
+            qmap[(0 if ry == 0 else rows // 2):(rows // 2 if ry == 0 else rows), (0 if rx == 0 else cols // 2):(cols // 2 if rx == 0 else cols)] = q
+        plane = synth.blocky_plane(w, h, seed=17 + bd, bit_depth=bd)
+        b = deblock.DeviceBatch(ctx, w, h, 1, bit_depth=bd)
+        b.upload_all(plane[None])
+        if seeded:
+            b.set_bs(0, rng.randint(0, 3, b.nv).astype(np.uint8), rng.randint(0, 3, b.nh).astype(np.uint8))
+        b.set_qp_map(qmap, log2)
+        ctx.filter_device(b.planes(), 0, variant=variant)
+        ctx.synchronize()
+        got = b.download_frame(0)
+        b.qp_map.free()
+        b.qp_map = None
+        p = b.planes()  # the same planes and bS arrays, no map: one QP per launch
+        m = 8
+        assert (got != plane).mean() > 0.05
+        for (ry, rx), q in qps.items():
+            ctx.filter_device(p, q, variant=variant)
+            ctx.synchronize()
+            want = b.download_frame(0)
+            y0, y1 = (0, by - m) if ry == 0 else (by + m, h)
+            x0, x1 = (0, bx - m) if rx == 0 else (bx + m, w)
+            assert np.array_equal(got[y0:y1, x0:x1], want[y0:y1, x0:x1]), (bd, log2, variant, seeded, ry, rx)
+            assert not np.array_equal(got, want)
+        b.free()
+
+
 def test_custom_tables(ctx, oracle, golden_inputs):
     y, _, _ = oracle.split_yuv420(golden_inputs["image1"], 352, 288)
     tc, beta = oracle.tables()
